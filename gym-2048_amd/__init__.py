@@ -1,0 +1,26 @@
+"""gym-2048_amd -- MI355X-native batched 2048 environment (import name: ``gym2048_amd``).
+
+The hot path of rgal/gym-2048 -- ``Game2048Env.step()/reset()`` and what they call -- as hand-written
+HIP kernels for gfx950 behind a C ABI (``include/g2048.h``), with the reference's Gymnasium surface on
+top.  See DESIGN.md / INTEGRATION.md.
+"""
+from ._lib import G2048Error, LIB_PATH  # noqa: F401
+from .env import Game2048Env, IllegalMove, stack  # noqa: F401
+from .vec_env import Vec2048  # noqa: F401
+from .sharding import Shard, shard_range, weak_shard, allgather_returns  # noqa: F401
+
+__version__ = "0.1.0"
+ENV_ID = "2048-v0"  # the reference's registration id (env/__init__.py:3-6)
+
+
+def __getattr__(name):
+    if name == "Batched2048":  # needs torch + a GPU; imported on first use
+        from .batched import Batched2048
+        return Batched2048
+    raise AttributeError(name)
+
+
+def register(entry_point: str = "gym2048_amd:Game2048Env"):
+    """Register ``'2048-v0'`` with gymnasium like the reference's ``env/__init__.py:1-6``."""
+    from gymnasium.envs.registration import register as _register
+    _register(id=ENV_ID, entry_point=entry_point)

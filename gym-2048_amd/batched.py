@@ -1,0 +1,362 @@
+"""``Batched2048`` -- N independent 2048 boards on one MI355X, driven through the C ABI.
+
+Host-side mirror of the reference's env object (``/root/reference/env/envs/game2048_env.py``,
+cited as ``game2048_env.py:LINE``) for a whole batch.  PyTorch-ROCm supplies device buffers and the
+current HIP stream; every compute step is a call into ``libg2048_hip.so``.
+
+Boards are ``uint8`` exponents (0 = empty, k = tile 2**k); ``tile_values()`` gives the reference's
+int64 tile values.  Actions: 0 up, 1 right, 2 down, 3 left (game2048_env.py:196).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import G2048Error, StepIO, Stats, check
+
+_ACTION_DTYPES = {torch.uint8: _lib.ACT_U8, torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}
+_OBS_DTYPES = {torch.uint8: _lib.OBS_U8, torch.float16: _lib.OBS_F16, torch.float32: _lib.OBS_F32}
+
+
+class _DeviceView:
+    """Minimal ``__cuda_array_interface__`` carrier for zero-copy torch views of engine memory."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def max_tile_to_exp(max_tile):
+    """set_max_tile argument (game2048_env.py:69-73) -> exponent, 0 for None."""
+    if max_tile is None:
+        return 0
+    if not isinstance(max_tile, (int, np.integer)):
+        raise AssertionError("max_tile must be None or an int")  # game2048_env.py:72
+    max_tile = int(max_tile)
+    exp = max_tile.bit_length() - 1
+    if max_tile < 2 or (1 << exp) != max_tile:
+        # the reference compares highest() == max_tile (game2048_env.py:267); a value that is not a
+        # tile can never be reached, which is "no limit"
+        return 0
+    return exp
+
+
+class Batched2048:
+    """``n_envs`` boards resident on ``cuda:device``; the batched counterpart of ``Game2048Env``.
+
+    Global board index of local board ``i`` is ``board_offset + i``: the spawn randomness is keyed
+    by the global index, so a batch sharded over several GPUs plays exactly the same games as the
+    same batch on one GPU.
+    """
+
+    def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
+                 illegal_move_reward: float = 0.0, max_tile=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if not torch.cuda.is_available():
+            raise G2048Error("Batched2048 needs a ROCm GPU (torch.cuda.is_available() is False); "
+                             "there is no CPU fallback")
+        self.n_envs = int(n_envs)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.board_offset = int(board_offset)
+        check(self._lib.g2048_create(self.n_envs, self.device_index, int(seed) & (2**64 - 1), self.board_offset,
+                                     C.byref(self._h)))
+        self._fresh = True
+        self.illegal_move_reward = 0.0
+        self.max_tile = None
+        self.set_illegal_move_reward(illegal_move_reward)
+        self.set_max_tile(max_tile)
+        n, dev = self.n_envs, self.device
+        # per-step outputs (reused every step; callers that need history pass their own buffers)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.illegal = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.highest = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.terminal_boards = torch.zeros((n, 16), dtype=torch.uint8, device=dev)
+        self._boards_view = None
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.g2048_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ configuration
+    def set_illegal_move_reward(self, reward: float):
+        """game2048_env.py:61-67."""
+        self.illegal_move_reward = float(reward)
+        check(self._lib.g2048_set_illegal_move_reward(self._h, self.illegal_move_reward))
+
+    def set_max_tile(self, max_tile):
+        """game2048_env.py:69-73."""
+        exp = max_tile_to_exp(max_tile)
+        self.max_tile = max_tile
+        check(self._lib.g2048_set_max_tile(self._h, exp))
+
+    def seed(self, seed: int):
+        """Seeding half of ``reset(seed=...)`` (game2048_env.py:103)."""
+        check(self._lib.g2048_seed(self._h, int(seed) & (2**64 - 1)))
+        self._fresh = True
+
+    @property
+    def clock(self) -> int:
+        t = C.c_uint64()
+        check(self._lib.g2048_get_clock(self._h, C.byref(t)))
+        return t.value
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, seed=None, mask=None, first_slot: int = 0, new_transaction=None):
+        """game2048_env.py:102-111 for every board (or those with ``mask != 0``)."""
+        if seed is not None:
+            self.seed(seed)
+        if new_transaction is None:
+            new_transaction = not self._fresh
+        mptr = None
+        if mask is not None:
+            mask = self._as_device(mask, torch.uint8)
+            mptr = C.c_void_p(mask.data_ptr())
+        check(self._lib.g2048_reset(self._h, int(bool(new_transaction)), int(first_slot), mptr, self._stream()))
+        self._fresh = False
+        return self.boards()
+
+    def _as_device(self, x, dtype=None):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.ascontiguousarray(x))
+        if dtype is not None and x.dtype != dtype:
+            x = x.to(dtype)
+        if x.device != self.device:
+            x = x.to(self.device)
+        return x.contiguous()
+
+    def _io(self, actions, reward, terminated, illegal, highest, terminal_boards):
+        io = StepIO()
+        if actions is None:
+            io.actions, io.action_dtype = None, _lib.ACT_RANDOM
+        else:
+            if actions.dtype not in _ACTION_DTYPES:
+                raise TypeError(f"actions dtype {actions.dtype} not supported (uint8, int32, int64)")
+            io.actions, io.action_dtype = actions.data_ptr(), _ACTION_DTYPES[actions.dtype]
+        for name, t in (("reward", reward), ("terminated", terminated), ("illegal", illegal),
+                        ("highest", highest), ("terminal_boards", terminal_boards)):
+            setattr(io, name, None if t is None else t.data_ptr())
+        return io
+
+    def step(self, actions=None, auto_reset: bool = True, want_info: bool = True):
+        """game2048_env.py:76-100 for every board; ``actions=None`` plays the synthetic random policy.
+
+        Returns ``(reward, terminated)`` device tensors (views of ``self.reward`` / ``self.terminated``,
+        overwritten by the next step).  With ``want_info`` also ``self.illegal``, ``self.highest`` and
+        -- for boards that terminated -- ``self.terminal_boards`` are filled.
+        """
+        if actions is not None:
+            actions = self._as_device(actions)
+            if actions.shape != (self.n_envs,):
+                raise ValueError(f"actions must have shape ({self.n_envs},), got {tuple(actions.shape)}")
+        io = self._io(actions, self.reward, self.terminated,
+                      self.illegal if want_info else None, self.highest if want_info else None,
+                      self.terminal_boards if want_info else None)
+        check(self._lib.g2048_step(self._h, C.byref(io), int(auto_reset), self._stream()))
+        self._fresh = False
+        return self.reward, self.terminated
+
+    def rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None, auto_reset: bool = True):
+        """``k`` steps without returning to Python: ``actions`` is ``[k, n]`` (or ``k`` as an int for
+        the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers."""
+        if isinstance(actions, int):
+            k, act = actions, None
+        else:
+            act = self._as_device(actions)
+            if act.dim() != 2 or act.shape[1] != self.n_envs:
+                raise ValueError("actions must be [k, n_envs]")
+            k = act.shape[0]
+        for t in (reward, terminated, illegal, highest):
+            if t is not None and (t.shape != (k, self.n_envs) or not t.is_contiguous() or t.device != self.device):
+                raise ValueError("rollout buffers must be contiguous [k, n_envs] tensors on the engine's device")
+        io = self._io(act, reward, terminated, illegal, highest, None)
+        check(self._lib.g2048_rollout(self._h, k, C.byref(io), self.n_envs, int(auto_reset), self._stream()))
+        self._fresh = False
+
+    def rollout_random(self, k_steps: int):
+        """ONE fused launch: ``k_steps`` of the synthetic random policy, boards kept in registers."""
+        check(self._lib.g2048_rollout_random(self._h, int(k_steps), self._stream()))
+        self._fresh = False
+
+    def random_actions(self, k_steps: int, t_first=None, out=None):
+        """uint8 ``[k_steps, n]`` actions of the synthetic policy for transactions ``t_first..``
+        (default: the next ``k_steps`` steps)."""
+        if t_first is None:
+            t_first = self.clock + 1
+        if out is None:
+            out = torch.empty((k_steps, self.n_envs), dtype=torch.uint8, device=self.device)
+        check(self._lib.g2048_fill_random_actions(self._h, int(t_first), int(k_steps), out.data_ptr(), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ observations
+    def boards(self) -> torch.Tensor:
+        """Zero-copy ``uint8 [n, 4, 4]`` view of the engine's board state (exponents)."""
+        if self._boards_view is None:
+            ptr = self._lib.g2048_boards_ptr(self._h)
+            view = torch.as_tensor(_DeviceView(ptr, (self.n_envs, 4, 4), "|u1"), device=self.device)
+            if view.data_ptr() != ptr:
+                raise G2048Error("torch did not alias the engine's board memory")
+            self._boards_view = view
+        return self._boards_view
+
+    def scores(self) -> torch.Tensor:
+        """Zero-copy ``int32 [n]`` view of the episodic merge scores (game2048_env.py:86)."""
+        ptr = self._lib.g2048_scores_ptr(self._h)
+        return torch.as_tensor(_DeviceView(ptr, (self.n_envs,), "<i4"), device=self.device)
+
+    def last_scores(self) -> torch.Tensor:
+        """Zero-copy ``int32 [n]``: final score of each board's most recently finished episode."""
+        ptr = self._lib.g2048_last_score_ptr(self._h)
+        return torch.as_tensor(_DeviceView(ptr, (self.n_envs,), "<i4"), device=self.device)
+
+    def tile_values(self) -> torch.Tensor:
+        """int64 ``[n, 4, 4]`` tile values as the reference holds them (game2048_env.py:104)."""
+        e = self.boards().to(torch.int64)
+        return torch.where(e > 0, torch.ones_like(e) << e, torch.zeros_like(e))
+
+    def observe_onehot(self, dtype=torch.uint8, out=None) -> torch.Tensor:
+        """``stack()`` (game2048_env.py:17-32) for the batch: ``[n, 16, 4, 4]`` of ``dtype``."""
+        if out is None:
+            out = torch.empty((self.n_envs, 16, 4, 4), dtype=dtype, device=self.device)
+        if out.dtype not in _OBS_DTYPES or tuple(out.shape) != (self.n_envs, 16, 4, 4) or not out.is_contiguous():
+            raise ValueError("one-hot output must be a contiguous [n,16,4,4] uint8/float16/float32 tensor")
+        check(self._lib.g2048_onehot(self._h, out.data_ptr(), _OBS_DTYPES[out.dtype], self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ host copies
+    def get_boards(self) -> np.ndarray:
+        """Host copy ``uint8 [n, 4, 4]`` (get_board, game2048_env.py:282-284)."""
+        buf = np.empty((self.n_envs, 4, 4), np.uint8)
+        check(self._lib.g2048_get_boards(self._h, buf.ctypes.data, self._stream()))
+        return buf
+
+    def set_boards(self, boards):
+        """set_board (game2048_env.py:286-288): ``uint8 [n,4,4]`` / ``[n,16]`` exponents, host or device."""
+        if isinstance(boards, torch.Tensor):
+            b = boards.to(torch.uint8).contiguous()
+            assert b.numel() == self.n_envs * 16
+            check(self._lib.g2048_set_boards(self._h, b.data_ptr(), self._stream()))
+        else:
+            b = np.ascontiguousarray(boards, dtype=np.uint8)
+            assert b.size == self.n_envs * 16
+            check(self._lib.g2048_set_boards(self._h, b.ctypes.data, self._stream()))
+
+    def get_scores(self) -> np.ndarray:
+        buf = np.empty(self.n_envs, np.int32)
+        check(self._lib.g2048_get_scores(self._h, buf.ctypes.data, self._stream()))
+        return buf
+
+    def set_scores(self, scores):
+        s = np.ascontiguousarray(scores, dtype=np.int32)
+        assert s.size == self.n_envs
+        check(self._lib.g2048_set_scores(self._h, s.ctypes.data, self._stream()))
+
+    def episode_records(self):
+        """Host copies ``(last_score int32[n], last_len int32[n], ep_count uint32[n])``."""
+        ls, ll = np.empty(self.n_envs, np.int32), np.empty(self.n_envs, np.int32)
+        ec = np.empty(self.n_envs, np.uint32)
+        check(self._lib.g2048_get_episode_records(self._h, ls.ctypes.data, ll.ctypes.data, ec.ctypes.data,
+                                                  self._stream()))
+        return ls, ll, ec
+
+    def episode_stats(self) -> dict:
+        st = Stats()
+        check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
+        return dict(episodes=st.episodes, score_sum=st.score_sum, length_sum=st.length_sum,
+                    max_score=st.max_score, max_exp=st.max_exp,
+                    mean_score=(st.score_sum / st.episodes) if st.episodes else 0.0,
+                    mean_length=(st.length_sum / st.episodes) if st.episodes else 0.0)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> dict:
+        nbytes = self._lib.g2048_state_bytes(self._h)
+        blob = np.empty(nbytes, np.uint8)
+        check(self._lib.g2048_get_state(self._h, blob.ctypes.data, self._stream()))
+        return {"blob": blob, "fresh": self._fresh}
+
+    def load_state_dict(self, state: dict):
+        blob = np.ascontiguousarray(state["blob"], dtype=np.uint8)
+        if blob.size != self._lib.g2048_state_bytes(self._h):
+            raise ValueError("state blob size does not match this engine")
+        check(self._lib.g2048_set_state(self._h, blob.ctypes.data, self._stream()))
+        self._fresh = bool(state.get("fresh", False))
+
+    # ------------------------------------------------------------------ numpy facade (used by the
+    # single-env and VecEnv adapters; tests replace this object by an oracle-backed fake)
+    def step_numpy(self, actions, auto_reset: bool = True) -> dict:
+        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int64))
+        self.step(a, auto_reset=auto_reset, want_info=True)
+        out = torch.stack([self.terminated, self.illegal, self.highest]).cpu().numpy()
+        return dict(reward=self.reward.cpu().numpy(), terminated=out[0].astype(bool), illegal=out[1].astype(bool),
+                    highest=out[2], terminal_boards=self.terminal_boards.cpu().numpy().reshape(-1, 4, 4))
+
+    def onehot_numpy(self) -> np.ndarray:
+        return self.observe_onehot(torch.uint8).cpu().numpy()
+
+    def move(self, actions, trial: bool = False):
+        """game2048_env.py:194-241 alone: returns device ``(score int32[n], legal uint8[n])``."""
+        a = self._as_device(actions)
+        if a.dtype not in _ACTION_DTYPES or a.shape != (self.n_envs,):
+            raise ValueError("actions must be a uint8/int32/int64 tensor of shape (n_envs,)")
+        score = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        legal = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
+        check(self._lib.g2048_move(self._h, a.data_ptr(), _ACTION_DTYPES[a.dtype], int(bool(trial)),
+                                   score.data_ptr(), legal.data_ptr(), self._stream()))
+        return score, legal
+
+    def move_numpy(self, actions, trial: bool = False):
+        score, legal = self.move(torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int64)), trial)
+        return score.cpu().numpy(), legal.cpu().numpy().astype(bool)
+
+    def query(self):
+        """Device ``(isend uint8[n], highest-exponent uint8[n])`` (game2048_env.py:262-280, :190-192)."""
+        end = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
+        hi = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
+        check(self._lib.g2048_query(self._h, end.data_ptr(), hi.data_ptr(), self._stream()))
+        return end, hi
+
+    def isend_numpy(self) -> np.ndarray:
+        return self.query()[0].cpu().numpy().astype(bool)
+
+    def highest_numpy(self) -> np.ndarray:
+        return self.query()[1].cpu().numpy()
+
+    def add_tile(self, slot: int):
+        """game2048_env.py:166-176 from spawn slot ``slot`` of the current transaction."""
+        check(self._lib.g2048_add_tile(self._h, int(slot), self._stream()))
+        self._fresh = False
+
+    def render(self, index: int = 0, mode: str = "ansi"):
+        from .render import render_board
+        vals = exp_to_values(self.get_boards()[index])
+        return render_board(vals, int(self.get_scores()[index]), mode)
+
+
+def exp_to_values(exps) -> np.ndarray:
+    e = np.asarray(exps).astype(np.int64)
+    return np.where(e > 0, np.int64(1) << e, np.int64(0))
+
+
+def values_to_exp(values) -> np.ndarray:
+    v = np.asarray(values).astype(np.int64)
+    if np.any(v < 0) or np.any((v & (v - 1)) != 0) or np.any(v == 1):
+        raise ValueError("board values must be 0 or powers of two >= 2")
+    out = np.zeros(v.shape, np.uint8)
+    nz = v > 0
+    out[nz] = np.floor(np.log2(v[nz]) + 0.5).astype(np.uint8)
+    return out

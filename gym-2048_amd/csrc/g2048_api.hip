@@ -1,0 +1,478 @@
+// g2048_api.hip -- the C ABI of include/g2048.h on top of the gfx950 kernels.
+// Host-side only: argument checking, the engine object, the transaction clock, launches.
+#include "../../include/g2048.h"
+
+#include "g2048_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define G2048_HIP(call)                                                                                        \
+    do {                                                                                                       \
+        hipError_t err_ = (call);                                                                              \
+        if (err_ != hipSuccess)                                                                                \
+            return fail(G2048_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(err_));                       \
+    } while (0)
+
+constexpr uint64_t kStateMagic = 0x3834303247ull; // "G2048"
+
+} // namespace
+
+struct g2048_engine {
+    uint64_t n = 0;
+    int device = 0;
+    uint64_t seed = 0;
+    uint64_t board_offset = 0;
+    uint64_t t = 0;       // transaction counter
+    int fresh = 1;        // nothing consumed from the stream since seeding
+    float illegal_reward = 0.0f; // game2048_env.py:53
+    uint32_t max_exp = 0;        // game2048_env.py:54 (0 = None)
+    void *slab = nullptr;
+    size_t slab_bytes = 0;
+    g2048::DeviceState st{};
+    g2048::StatsOut *stats_dev = nullptr;
+};
+
+namespace {
+
+struct StateHeader {
+    uint64_t magic, n, seed, board_offset, t;
+    int32_t fresh;
+    uint32_t max_exp;
+    float illegal_reward;
+    uint32_t reserved;
+};
+
+size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int auto_reset)
+{
+    g2048::StepArgs a{};
+    a.st = e->st;
+    if (io) {
+        a.actions = io->actions;
+        a.reward = io->reward;
+        a.terminated = io->terminated;
+        a.illegal = io->illegal;
+        a.highest = io->highest;
+        a.terminal_boards = reinterpret_cast<uint4 *>(io->terminal_boards);
+    }
+    a.n = static_cast<uint32_t>(e->n);
+    a.board_offset = static_cast<uint32_t>(e->board_offset);
+    a.seed_lo = static_cast<uint32_t>(e->seed);
+    a.seed_hi = static_cast<uint32_t>(e->seed >> 32);
+    a.t_lo = static_cast<uint32_t>(e->t);
+    a.t_hi = static_cast<uint32_t>(e->t >> 32);
+    a.illegal_reward = e->illegal_reward;
+    a.max_exp = e->max_exp;
+    a.auto_reset = auto_reset ? 1u : 0u;
+    return a;
+}
+
+int check_io(const g2048_step_io *io)
+{
+    if (!io)
+        return fail(G2048_ERR_INVALID, "io is NULL");
+    if (io->action_dtype < G2048_ACT_RANDOM || io->action_dtype > G2048_ACT_I64)
+        return fail(G2048_ERR_INVALID, "unknown action_dtype %d", io->action_dtype);
+    if (io->action_dtype != G2048_ACT_RANDOM && !io->actions)
+        return fail(G2048_ERR_INVALID, "actions is NULL but action_dtype is %d", io->action_dtype);
+    return G2048_OK;
+}
+
+size_t action_size(int dtype)
+{
+    switch (dtype) {
+    case G2048_ACT_U8: return 1;
+    case G2048_ACT_I32: return 4;
+    case G2048_ACT_I64: return 8;
+    default: return 0;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *g2048_last_error(void) { return g_error; }
+
+int g2048_abi_version(void) { return 1; }
+
+int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
+{
+    if (!out)
+        return fail(G2048_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_boards == 0 || n_boards > 0xffffffffull || board_offset + n_boards > 0x100000000ull)
+        return fail(G2048_ERR_INVALID, "n_boards=%llu board_offset=%llu: global board indices must fit 32 bits",
+                    (unsigned long long)n_boards, (unsigned long long)board_offset);
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count == 0)
+        return fail(G2048_ERR_HIP, "no HIP device available (%s); this library has no CPU path",
+                    err != hipSuccess ? hipGetErrorString(err) : "device count is 0");
+    if (device < 0 || device >= count)
+        return fail(G2048_ERR_INVALID, "device %d out of range (have %d)", device, count);
+    G2048_HIP(hipSetDevice(device));
+
+    g2048_engine *e = new (std::nothrow) g2048_engine;
+    if (!e)
+        return fail(G2048_ERR_NOMEM, "out of host memory");
+    e->n = n_boards;
+    e->device = device;
+    e->seed = seed;
+    e->board_offset = board_offset;
+
+    const size_t n = n_boards;
+    const size_t off_boards = 0;
+    const size_t off_score = off_boards + align_up(n * 16);
+    const size_t off_ep_start = off_score + align_up(n * 4);
+    const size_t off_last_score = off_ep_start + align_up(n * 4);
+    const size_t off_last_len = off_last_score + align_up(n * 4);
+    const size_t off_ep_count = off_last_len + align_up(n * 4);
+    const size_t off_score_sum = off_ep_count + align_up(n * 4);
+    const size_t off_len_sum = off_score_sum + align_up(n * 8);
+    const size_t off_stats = off_len_sum + align_up(n * 8);
+    e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
+    err = hipMalloc(&e->slab, e->slab_bytes);
+    if (err != hipSuccess) {
+        delete e;
+        return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", e->slab_bytes, hipGetErrorString(err));
+    }
+    err = hipMemset(e->slab, 0, e->slab_bytes);
+    if (err != hipSuccess) {
+        (void)hipFree(e->slab);
+        delete e;
+        return fail(G2048_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err));
+    }
+    char *base = static_cast<char *>(e->slab);
+    e->st.boards = reinterpret_cast<uint4 *>(base + off_boards);
+    e->st.score = reinterpret_cast<int32_t *>(base + off_score);
+    e->st.ep_start = reinterpret_cast<uint32_t *>(base + off_ep_start);
+    e->st.last_score = reinterpret_cast<int32_t *>(base + off_last_score);
+    e->st.last_len = reinterpret_cast<int32_t *>(base + off_last_len);
+    e->st.ep_count = reinterpret_cast<uint32_t *>(base + off_ep_count);
+    e->st.score_sum = reinterpret_cast<int64_t *>(base + off_score_sum);
+    e->st.len_sum = reinterpret_cast<int64_t *>(base + off_len_sum);
+    e->stats_dev = reinterpret_cast<g2048::StatsOut *>(base + off_stats);
+    *out = e;
+    return G2048_OK;
+}
+
+int g2048_destroy(g2048_engine *e)
+{
+    if (!e)
+        return G2048_OK;
+    hipError_t err = hipSuccess;
+    if (e->slab) {
+        (void)hipSetDevice(e->device);
+        err = hipFree(e->slab);
+    }
+    delete e;
+    if (err != hipSuccess)
+        return fail(G2048_ERR_HIP, "hipFree failed: %s", hipGetErrorString(err));
+    return G2048_OK;
+}
+
+int g2048_seed(g2048_engine *e, uint64_t seed)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    e->seed = seed;
+    e->t = 0;
+    e->fresh = 1;
+    return G2048_OK;
+}
+
+int g2048_get_clock(const g2048_engine *e, uint64_t *t)
+{
+    if (!e || !t)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    *t = e->t;
+    return G2048_OK;
+}
+
+int g2048_set_clock(g2048_engine *e, uint64_t t)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    e->t = t;
+    e->fresh = 0;
+    return G2048_OK;
+}
+
+uint64_t g2048_num_boards(const g2048_engine *e) { return e ? e->n : 0; }
+
+int g2048_set_illegal_move_reward(g2048_engine *e, float reward)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    e->illegal_reward = reward;
+    return G2048_OK;
+}
+
+int g2048_set_max_tile(g2048_engine *e, int max_exp)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (max_exp < 0 || max_exp > 31)
+        return fail(G2048_ERR_INVALID, "max_exp %d out of range 0..31", max_exp);
+    e->max_exp = static_cast<uint32_t>(max_exp);
+    return G2048_OK;
+}
+
+int g2048_reset(g2048_engine *e, int new_transaction, uint32_t first_slot, const uint8_t *mask, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    G2048_HIP(hipSetDevice(e->device));
+    if (new_transaction)
+        e->t += 1;
+    e->fresh = 0;
+    const g2048::StepArgs a = make_args(e, nullptr, 0);
+    G2048_HIP(g2048::launch_reset(a, first_slot, mask, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = check_io(io))
+        return rc;
+    G2048_HIP(hipSetDevice(e->device));
+    e->t += 1;
+    e->fresh = 0;
+    const g2048::StepArgs a = make_args(e, io, auto_reset);
+    G2048_HIP(g2048::launch_step(a, io->action_dtype, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
+                  void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = check_io(io))
+        return rc;
+    G2048_HIP(hipSetDevice(e->device));
+    const size_t asz = action_size(io->action_dtype);
+    for (uint32_t j = 0; j < k_steps; ++j) {
+        g2048_step_io s = *io;
+        const size_t off = static_cast<size_t>(j) * stride;
+        if (s.actions) s.actions = static_cast<const char *>(io->actions) + off * asz;
+        if (s.reward) s.reward = io->reward + off;
+        if (s.terminated) s.terminated = io->terminated + off;
+        if (s.illegal) s.illegal = io->illegal + off;
+        if (s.highest) s.highest = io->highest + off;
+        if (s.terminal_boards) s.terminal_boards = io->terminal_boards + off * 16;
+        e->t += 1;
+        e->fresh = 0;
+        const g2048::StepArgs a = make_args(e, &s, auto_reset);
+        G2048_HIP(g2048::launch_step(a, s.action_dtype, static_cast<hipStream_t>(stream)));
+    }
+    return G2048_OK;
+}
+
+int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (k_steps == 0)
+        return G2048_OK;
+    G2048_HIP(hipSetDevice(e->device));
+    e->t += 1; // transaction of the first fused step
+    e->fresh = 0;
+    g2048::StepArgs a = make_args(e, nullptr, 1);
+    a.k_steps = k_steps;
+    G2048_HIP(g2048::launch_rollout_random(a, static_cast<hipStream_t>(stream)));
+    e->t += k_steps - 1;
+    return G2048_OK;
+}
+
+int g2048_move(g2048_engine *e, const void *actions, int32_t action_dtype, int trial, int32_t *score_out,
+               uint8_t *legal_out, void *stream)
+{
+    if (!e || !actions)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    if (action_dtype < G2048_ACT_U8 || action_dtype > G2048_ACT_I64)
+        return fail(G2048_ERR_INVALID, "g2048_move needs an action buffer (dtype %d)", action_dtype);
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(g2048::launch_move(e->st.boards, static_cast<uint32_t>(e->n), actions, action_dtype, trial != 0,
+                                 score_out, legal_out, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_query(const g2048_engine *e, uint8_t *isend_out, uint8_t *highest_out, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(g2048::launch_query(e->st.boards, static_cast<uint32_t>(e->n), e->max_exp, isend_out, highest_out,
+                                  static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_add_tile(g2048_engine *e, uint32_t slot, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    G2048_HIP(hipSetDevice(e->device));
+    e->fresh = 0;
+    const g2048::StepArgs a = make_args(e, nullptr, 0);
+    G2048_HIP(g2048::launch_add_tile(a, slot, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_fill_random_actions(const g2048_engine *e, uint64_t t_first, uint32_t k_steps, uint8_t *out, void *stream)
+{
+    if (!e || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(g2048::launch_fill_actions(out, static_cast<uint32_t>(e->n), static_cast<uint32_t>(e->board_offset),
+                                         static_cast<uint32_t>(e->seed), static_cast<uint32_t>(e->seed >> 32),
+                                         t_first, k_steps, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_onehot(const g2048_engine *e, void *out, int32_t obs_dtype, void *stream)
+{
+    if (!e || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    if (obs_dtype < G2048_OBS_U8 || obs_dtype > G2048_OBS_F32)
+        return fail(G2048_ERR_INVALID, "unknown obs_dtype %d", obs_dtype);
+    if (reinterpret_cast<uintptr_t>(out) & 15u)
+        return fail(G2048_ERR_INVALID, "one-hot output must be 16-byte aligned");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(g2048::launch_onehot(e->st.boards, static_cast<uint32_t>(e->n), out, obs_dtype,
+                                   static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+static int copy_out(const g2048_engine *e, void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!e || !dst)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
+    G2048_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+static int copy_in(g2048_engine *e, void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!e || !src)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
+    G2048_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_get_boards(const g2048_engine *e, uint8_t *buf, void *stream)
+{
+    return copy_out(e, buf, e ? e->st.boards : nullptr, e ? e->n * 16 : 0, stream);
+}
+
+int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream)
+{
+    return copy_in(e, e ? e->st.boards : nullptr, buf, e ? e->n * 16 : 0, stream);
+}
+
+int g2048_get_scores(const g2048_engine *e, int32_t *buf, void *stream)
+{
+    return copy_out(e, buf, e ? e->st.score : nullptr, e ? e->n * 4 : 0, stream);
+}
+
+int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
+{
+    return copy_in(e, e ? e->st.score : nullptr, buf, e ? e->n * 4 : 0, stream);
+}
+
+int g2048_get_episode_records(const g2048_engine *e, int32_t *last_score, int32_t *last_len, uint32_t *ep_count,
+                              void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (last_score)
+        if (int rc = copy_out(e, last_score, e->st.last_score, e->n * 4, stream))
+            return rc;
+    if (last_len)
+        if (int rc = copy_out(e, last_len, e->st.last_len, e->n * 4, stream))
+            return rc;
+    if (ep_count)
+        if (int rc = copy_out(e, ep_count, e->st.ep_count, e->n * 4, stream))
+            return rc;
+    return G2048_OK;
+}
+
+void *g2048_boards_ptr(const g2048_engine *e) { return e ? e->st.boards : nullptr; }
+void *g2048_scores_ptr(const g2048_engine *e) { return e ? e->st.score : nullptr; }
+void *g2048_last_score_ptr(const g2048_engine *e) { return e ? e->st.last_score : nullptr; }
+
+int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
+{
+    if (!e || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_dev, s));
+    g2048::StatsOut h{};
+    G2048_HIP(hipMemcpyAsync(&h, e->stats_dev, sizeof h, hipMemcpyDeviceToHost, s));
+    G2048_HIP(hipStreamSynchronize(s));
+    out->episodes = h.episodes;
+    out->score_sum = h.score_sum;
+    out->length_sum = h.length_sum;
+    out->max_score = h.max_score;
+    out->max_exp = h.max_exp;
+    return G2048_OK;
+}
+
+uint64_t g2048_state_bytes(const g2048_engine *e)
+{
+    return e ? sizeof(StateHeader) + e->slab_bytes : 0;
+}
+
+int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream)
+{
+    if (!e || !host_buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    StateHeader h{kStateMagic, e->n, e->seed, e->board_offset, e->t, e->fresh, e->max_exp, e->illegal_reward, 0};
+    std::memcpy(host_buf, &h, sizeof h);
+    return copy_out(e, static_cast<char *>(host_buf) + sizeof h, e->slab, e->slab_bytes, stream);
+}
+
+int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream)
+{
+    if (!e || !host_buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    StateHeader h;
+    std::memcpy(&h, host_buf, sizeof h);
+    if (h.magic != kStateMagic || h.n != e->n)
+        return fail(G2048_ERR_INVALID, "state blob does not match this engine (magic %llx, n %llu vs %llu)",
+                    (unsigned long long)h.magic, (unsigned long long)h.n, (unsigned long long)e->n);
+    e->seed = h.seed;
+    e->board_offset = h.board_offset;
+    e->t = h.t;
+    e->fresh = h.fresh;
+    e->max_exp = h.max_exp;
+    e->illegal_reward = h.illegal_reward;
+    return copy_in(e, e->slab, static_cast<const char *>(host_buf) + sizeof h, e->slab_bytes, stream);
+}
+
+} // extern "C"

@@ -1,0 +1,61 @@
+// g2048_kernels.h -- launch interface between the C ABI (g2048_api.hip) and the gfx950 kernels
+// (g2048_kernels.hip).  Internal; the public contract is include/g2048.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace g2048 {
+
+// Engine-owned device state (one slab).
+struct DeviceState {
+    uint4 *boards;        // [n]   16 x int8 exponents per board
+    int32_t *score;       // [n]   episodic merge score (game2048_env.py:86)
+    uint32_t *ep_start;   // [n]   low 32 bits of the transaction that started the episode
+    int32_t *last_score;  // [n]   record of the last finished episode
+    int32_t *last_len;    // [n]
+    uint32_t *ep_count;   // [n]   finished episodes
+    int64_t *score_sum;   // [n]   sum of final scores over finished episodes
+    int64_t *len_sum;     // [n]
+};
+
+struct StepArgs {
+    DeviceState st;
+    const void *actions;
+    float *reward;
+    uint8_t *terminated;
+    uint8_t *illegal;
+    uint8_t *highest;
+    uint4 *terminal_boards;
+    uint32_t n;
+    uint32_t board_offset;
+    uint32_t seed_lo, seed_hi;
+    uint32_t t_lo, t_hi;
+    float illegal_reward;
+    uint32_t max_exp;
+    uint32_t auto_reset;
+    uint32_t k_steps; // fused rollout only
+};
+
+struct StatsOut {
+    unsigned long long episodes;
+    long long score_sum;
+    long long length_sum;
+    int max_score;
+    unsigned int max_exp;
+};
+
+hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s);
+hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s);
+hipError_t launch_rollout_random(const StepArgs &a, hipStream_t s);
+hipError_t launch_move(uint4 *boards, uint32_t n, const void *actions, int action_dtype, bool trial,
+                       int32_t *score_out, uint8_t *legal_out, hipStream_t s);
+hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8_t *isend_out, uint8_t *highest_out,
+                        hipStream_t s);
+hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s);
+hipError_t launch_fill_actions(uint8_t *out, uint32_t n, uint32_t board_offset, uint32_t seed_lo, uint32_t seed_hi,
+                               uint64_t t_first, uint32_t k_steps, hipStream_t s);
+hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dtype, hipStream_t s);
+hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hipStream_t s);
+
+} // namespace g2048

@@ -1,0 +1,401 @@
+// g2048_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched 2048 environment.
+//
+// Mapping: ONE BOARD PER LANE.  A wavefront owns 64 consecutive boards = 1 KiB of board state, read
+// and written with one global_load/store_dwordx4 per lane (fully coalesced, 16 B/lane).  The whole
+// step -- slide/merge sweep, score, spawn, done detection, auto-reset -- runs out of VGPRs with
+// byte-parallel integer ops (g2048_device.h); there is no cross-lane traffic, no LDS and no
+// per-board RNG state: the spawn randomness of (transaction t, board b) is one Philox4x32-10 block.
+//
+// HBM bytes per env-step of step_kernel (the roofline figure in DESIGN.md):
+//   algorithmic 38 B = board in 16 + action 1 + board out 16 + reward 4 + terminated 1
+//   plus the episodic score state (4 B in + 4 B out) and, only for boards that terminate, the
+//   episode record.
+#include "g2048_kernels.h"
+
+#include "g2048_device.h"
+
+namespace g2048 {
+
+constexpr int kBlock = 256;
+
+template <int ACT>
+__device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i, uint32_t w3)
+{
+    if constexpr (ACT == 0)
+        return w3 >> 30;
+    else if constexpr (ACT == 1)
+        return static_cast<const uint8_t *>(actions)[i] & 3u;
+    else if constexpr (ACT == 2)
+        return static_cast<uint32_t>(static_cast<const int32_t *>(actions)[i]) & 3u;
+    else
+        return static_cast<uint32_t>(static_cast<const long long *>(actions)[i]) & 3u;
+}
+
+// Episode bookkeeping for a board whose step terminated: the record of the finished episode
+// (touched only by the ~7 % of lanes that end an episode under a random policy).
+__device__ __forceinline__ void record_episode(const StepArgs &p, uint32_t i, const StepResult &r, uint32_t t_lo)
+{
+    if (p.terminal_boards)
+        p.terminal_boards[i] = make_uint4(r.terminal.r[0], r.terminal.r[1], r.terminal.r[2], r.terminal.r[3]);
+    const int32_t len = static_cast<int32_t>(t_lo - p.st.ep_start[i]);
+    p.st.last_score[i] = r.terminal_score;
+    p.st.last_len[i] = len;
+    p.st.ep_count[i] += 1u;
+    p.st.score_sum[i] += r.terminal_score;
+    p.st.len_sum[i] += len;
+    if (p.auto_reset)
+        p.st.ep_start[i] = t_lo;
+}
+
+// ---------------------------------------------------------------------------------- step
+// Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
+template <int ACT>
+__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n)
+        return;
+    const uint4 v = p.st.boards[i];
+    Board bd{{v.x, v.y, v.z, v.w}};
+    int32_t score = p.st.score[i];
+
+    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+    const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
+
+    const StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+
+    if (p.reward)
+        p.reward[i] = r.reward;
+    if (p.terminated)
+        p.terminated[i] = r.terminated ? 1 : 0;
+    if (p.illegal)
+        p.illegal[i] = r.illegal ? 1 : 0;
+    if (p.highest)
+        p.highest[i] = static_cast<uint8_t>(highest(r.terminal)); // :97
+    if (r.terminated)
+        record_episode(p, i, r, p.t_lo);
+
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    p.st.score[i] = score;
+}
+
+// ------------------------------------------------------------------------- fused rollout
+// k steps of the synthetic random policy in ONE launch; the board never leaves registers.
+__global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n)
+        return;
+    const uint4 v = p.st.boards[i];
+    Board bd{{v.x, v.y, v.z, v.w}};
+    int32_t score = p.st.score[i];
+    uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
+    for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
+        const uint32_t t_lo = static_cast<uint32_t>(t), t_hi = static_cast<uint32_t>(t >> 32);
+        const Words w = philox4x32_10(t_lo, t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+        const StepResult r = step_env(bd, score, w.w[3] >> 30, w, p.illegal_reward, p.max_exp, true);
+        if (r.terminated)
+            record_episode(p, i, r, t_lo);
+    }
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    p.st.score[i] = score;
+}
+
+// ---------------------------------------------------------------------------------- reset
+// Game2048Env.reset for every (masked) board (game2048_env.py:102-111).
+__global__ void __launch_bounds__(kBlock) reset_kernel(const StepArgs p, uint32_t first_slot, const uint8_t *mask)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n)
+        return;
+    if (mask && mask[i] == 0)
+        return;
+    const uint32_t b = p.board_offset + i;
+    const Words w = philox4x32_10(p.t_lo, p.t_hi, b, first_slot >> 2, p.seed_lo, p.seed_hi);
+    const uint32_t s = first_slot & 3u;
+    const uint32_t w1 = select_word(w, s);
+    uint32_t w2;
+    if (s == 3u) // the second spawn lives in the next block of this transaction
+        w2 = philox4x32_10(p.t_lo, p.t_hi, b, (first_slot >> 2) + 1u, p.seed_lo, p.seed_hi).w[0];
+    else
+        w2 = select_word(w, s + 1u);
+    const Board bd = fresh_board(w1, w2);
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    p.st.score[i] = 0; // :105
+    p.st.ep_start[i] = p.t_lo;
+}
+
+// ------------------------------------------------------------------------- game primitives
+// Game2048Env.move alone (game2048_env.py:194-241): no spawn, no score, no clock.
+template <int ACT>
+__global__ void __launch_bounds__(kBlock) move_kernel(uint4 *boards, uint32_t n, const void *actions, uint32_t trial,
+                                                      int32_t *score_out, uint8_t *legal_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint4 v = boards[i];
+    Board bd{{v.x, v.y, v.z, v.w}};
+    uint32_t gain;
+    const bool legal = move(bd, load_action<ACT>(actions, i, 0u), gain);
+    if (score_out)
+        score_out[i] = legal ? static_cast<int32_t>(gain) : 0;
+    if (legal_out)
+        legal_out[i] = legal ? 1 : 0;
+    if (!trial && legal)
+        boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+}
+
+// Game2048Env.isend (game2048_env.py:262-280) and highest (:190-192).
+__global__ void __launch_bounds__(kBlock) query_kernel(const uint4 *boards, uint32_t n, uint32_t max_exp,
+                                                       uint8_t *isend_out, uint8_t *highest_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint4 v = boards[i];
+    const Board bd{{v.x, v.y, v.z, v.w}};
+    if (isend_out)
+        isend_out[i] = is_end(bd, max_exp) ? 1 : 0;
+    if (highest_out)
+        highest_out[i] = static_cast<uint8_t>(highest(bd));
+}
+
+// Game2048Env.add_tile (game2048_env.py:166-176) from spawn slot `slot` of transaction t.
+__global__ void __launch_bounds__(kBlock) add_tile_kernel(const StepArgs p, uint32_t slot)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n)
+        return;
+    const uint4 v = p.st.boards[i];
+    Board bd{{v.x, v.y, v.z, v.w}};
+    if (count_empty(bd) == 0) // the reference asserts here (:176)
+        return;
+    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, slot >> 2, p.seed_lo, p.seed_hi);
+    add_tile(bd, select_word(w, slot & 3u));
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+}
+
+// ------------------------------------------------------------------------ synthetic policy
+__global__ void __launch_bounds__(kBlock) fill_actions_kernel(uint8_t *out, uint32_t n, uint32_t board_offset,
+                                                              uint32_t seed_lo, uint32_t seed_hi, uint64_t t_first,
+                                                              uint32_t k_steps)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= n || j >= k_steps)
+        return;
+    const uint64_t t = t_first + j;
+    const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), board_offset + i, 0u,
+                                  seed_lo, seed_hi);
+    out[static_cast<size_t>(j) * n + i] = static_cast<uint8_t>(w.w[3] >> 30);
+}
+
+// ---------------------------------------------------------------------------------- onehot
+// stack() (game2048_env.py:17-32): board -> (16,4,4), channel c = (exponent == c).  One lane writes
+// one 16-byte chunk of the output, so every store is a coalesced dwordx4:
+//   u8 : chunk = one channel (16 cells)            16 chunks / board
+//   f16: chunk = half a channel (8 cells)          32 chunks / board
+//   f32: chunk = one row of one channel (4 cells)  64 chunks / board
+template <int OBS>
+__global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict__ boards, uint64_t chunks,
+                                                        uint4 *__restrict__ out)
+{
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= chunks)
+        return;
+    const uint32_t *cells = reinterpret_cast<const uint32_t *>(boards);
+    if constexpr (OBS == 0) {
+        const uint64_t board = g >> 4;
+        const uint32_t splat = static_cast<uint32_t>(g & 15u) * 0x01010101u;
+        const uint4 v = boards[board];
+        out[g] = make_uint4(z80(v.x ^ splat) >> 7, z80(v.y ^ splat) >> 7, z80(v.z ^ splat) >> 7,
+                            z80(v.w ^ splat) >> 7);
+    } else if constexpr (OBS == 1) {
+        const uint64_t board = g >> 5;
+        const uint32_t c = static_cast<uint32_t>(g >> 1) & 15u, half = static_cast<uint32_t>(g) & 1u;
+        const uint32_t r0 = cells[board * 4 + half * 2], r1 = cells[board * 4 + half * 2 + 1];
+        uint32_t h[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (((r0 >> (8 * k)) & 0xffu) == c) ? 0x3c00u : 0u; // fp16 1.0
+            h[4 + k] = (((r1 >> (8 * k)) & 0xffu) == c) ? 0x3c00u : 0u;
+        }
+        out[g] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    } else {
+        const uint64_t board = g >> 6;
+        const uint32_t c = static_cast<uint32_t>(g >> 2) & 15u, row = static_cast<uint32_t>(g) & 3u;
+        const uint32_t r = cells[board * 4 + row];
+        uint32_t f[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            f[k] = (((r >> (8 * k)) & 0xffu) == c) ? 0x3f800000u : 0u; // fp32 1.0
+        out[g] = make_uint4(f[0], f[1], f[2], f[3]);
+    }
+}
+
+// ----------------------------------------------------------------------------------- stats
+__device__ __forceinline__ long long wave_sum(long long x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        x += __shfl_down(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ int wave_max(int x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        x = max(x, __shfl_down(x, off, 64));
+    return x;
+}
+
+__global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, StatsOut *out)
+{
+    long long episodes = 0, score_sum = 0, len_sum = 0;
+    int max_score = 0, max_exp = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t c = st.ep_count[i];
+        episodes += c;
+        score_sum += st.score_sum[i];
+        len_sum += st.len_sum[i];
+        if (c)
+            max_score = max(max_score, st.last_score[i]);
+        const uint4 v = st.boards[i];
+        max_exp = max(max_exp, static_cast<int>(highest(Board{{v.x, v.y, v.z, v.w}})));
+    }
+    episodes = wave_sum(episodes);
+    score_sum = wave_sum(score_sum);
+    len_sum = wave_sum(len_sum);
+    max_score = wave_max(max_score);
+    max_exp = wave_max(max_exp);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out->episodes, static_cast<unsigned long long>(episodes));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&out->score_sum), static_cast<unsigned long long>(score_sum));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&out->length_sum), static_cast<unsigned long long>(len_sum));
+        atomicMax(&out->max_score, max_score);
+        atomicMax(&out->max_exp, static_cast<unsigned int>(max_exp));
+    }
+}
+
+// -------------------------------------------------------------------------------- launchers
+static inline dim3 grid_for(uint64_t items) { return dim3(static_cast<uint32_t>((items + kBlock - 1) / kBlock)); }
+
+hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s)
+{
+    if (a.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(reset_kernel, grid_for(a.n), dim3(kBlock), 0, s, a, first_slot, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
+{
+    if (a.n == 0)
+        return hipSuccess;
+    const dim3 g = grid_for(a.n), b(kBlock);
+    switch (action_dtype) {
+    case 0: hipLaunchKernelGGL(step_kernel<0>, g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL(step_kernel<1>, g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(step_kernel<2>, g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(step_kernel<3>, g, b, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_move(uint4 *boards, uint32_t n, const void *actions, int action_dtype, bool trial,
+                       int32_t *score_out, uint8_t *legal_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const dim3 g = grid_for(n), b(kBlock);
+    const uint32_t tr = trial ? 1u : 0u;
+    switch (action_dtype) {
+    case 1: hipLaunchKernelGGL(move_kernel<1>, g, b, 0, s, boards, n, actions, tr, score_out, legal_out); break;
+    case 2: hipLaunchKernelGGL(move_kernel<2>, g, b, 0, s, boards, n, actions, tr, score_out, legal_out); break;
+    case 3: hipLaunchKernelGGL(move_kernel<3>, g, b, 0, s, boards, n, actions, tr, score_out, legal_out); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8_t *isend_out, uint8_t *highest_out,
+                        hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(query_kernel, grid_for(n), dim3(kBlock), 0, s, boards, n, max_exp, isend_out, highest_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s)
+{
+    if (a.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(add_tile_kernel, grid_for(a.n), dim3(kBlock), 0, s, a, slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_random(const StepArgs &a, hipStream_t s)
+{
+    if (a.n == 0 || a.k_steps == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(rollout_random_kernel, grid_for(a.n), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_actions(uint8_t *out, uint32_t n, uint32_t board_offset, uint32_t seed_lo, uint32_t seed_hi,
+                               uint64_t t_first, uint32_t k_steps, hipStream_t s)
+{
+    if (n == 0 || k_steps == 0)
+        return hipSuccess;
+    // gridDim.y is limited to 65535: walk the step axis in slabs.
+    for (uint32_t j0 = 0; j0 < k_steps; j0 += 32768u) {
+        const uint32_t kj = (k_steps - j0 < 32768u) ? (k_steps - j0) : 32768u;
+        dim3 g(grid_for(n).x, kj);
+        hipLaunchKernelGGL(fill_actions_kernel, g, dim3(kBlock), 0, s, out + static_cast<size_t>(j0) * n, n,
+                           board_offset, seed_lo, seed_hi, t_first + j0, kj);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dtype, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    uint4 *o = static_cast<uint4 *>(out);
+    switch (obs_dtype) {
+    case 0: {
+        const uint64_t chunks = static_cast<uint64_t>(n) * 16;
+        hipLaunchKernelGGL(onehot_kernel<0>, grid_for(chunks), dim3(kBlock), 0, s, boards, chunks, o);
+        break;
+    }
+    case 1: {
+        const uint64_t chunks = static_cast<uint64_t>(n) * 32;
+        hipLaunchKernelGGL(onehot_kernel<1>, grid_for(chunks), dim3(kBlock), 0, s, boards, chunks, o);
+        break;
+    }
+    case 2: {
+        const uint64_t chunks = static_cast<uint64_t>(n) * 64;
+        hipLaunchKernelGGL(onehot_kernel<2>, grid_for(chunks), dim3(kBlock), 0, s, boards, chunks, o);
+        break;
+    }
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hipStream_t s)
+{
+    hipError_t err = hipMemsetAsync(dev_out, 0, sizeof(StatsOut), s);
+    if (err != hipSuccess || n == 0)
+        return err;
+    uint32_t blocks = grid_for(n).x;
+    if (blocks > 2048u)
+        blocks = 2048u;
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, dev_out);
+    return hipGetLastError();
+}
+
+} // namespace g2048

@@ -1,0 +1,207 @@
+"""``Game2048Env`` -- the reference's single-env Gymnasium surface, served by the HIP engine.
+
+Drop-in for ``env.envs.game2048_env.Game2048Env`` (game2048_env.py:34-288): same constructor,
+``reset/step/render``, setters, test hooks and attributes.  The env is an N = 1 view over
+``Batched2048``; every game computation (move, shift, spawn, done, one-hot) runs in
+``libg2048_hip.so`` -- this file only converts formats (int64 tile values <-> uint8 exponents).
+
+Randomness: the spawn stream (include/g2048.h).  ``reset(seed=s)`` restarts it; ``reset()``
+continues it, as gymnasium does (game2048_env.py:103).  An env that was never seeded draws a seed
+from the OS, like gymnasium.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .render import GRID_SIZE, render_board
+
+
+class IllegalMove(Exception):
+    """game2048_env.py:14-15."""
+
+
+def stack(flat, layers=15):
+    """game2048_env.py:17-32: (4,4) tile values -> (layers+1,4,4) one-hot (host arrays; the batched
+    device version is ``Batched2048.observe_onehot``)."""
+    flat = np.asarray(flat)
+    targets = np.concatenate([[0], 2 ** (np.arange(layers, dtype=np.int64) + 1)])
+    return (flat[np.newaxis, :, :] == targets[:, np.newaxis, np.newaxis]).astype(int)
+
+
+class _Space:
+    """Stand-in used only when gymnasium is not installed."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def contains(self, x):
+        return True
+
+
+def make_spaces():
+    """(action_space, observation_space) as game2048_env.py:49-52."""
+    try:
+        from gymnasium import spaces
+        return spaces.Discrete(4), spaces.Box(0, 1, (16, 4, 4), dtype=int)
+    except ImportError:
+        return _Space(n=4, shape=(), dtype=np.int64), _Space(low=0, high=1, shape=(16, 4, 4), dtype=np.dtype(int))
+
+
+def _exp_to_values(e):
+    e = np.asarray(e).astype(np.int64)
+    return np.where(e > 0, np.int64(1) << e, np.int64(0))
+
+
+def _values_to_exp(v):
+    v = np.asarray(v).astype(np.int64)
+    out = np.zeros(v.shape, np.uint8)
+    nz = v > 0
+    out[nz] = np.floor(np.log2(v[nz]) + 0.5).astype(np.uint8)
+    return out
+
+
+class Game2048Env:
+    metadata = {"render_modes": ["ansi", "human", "rgb_array"], "render_fps": 4}  # game2048_env.py:35
+    _all_positions = [(r, c) for r in range(4) for c in range(4)]                  # game2048_env.py:36
+
+    def __init__(self, render_mode=None, *, device: int = 0, engine=None):
+        # game2048_env.py:38-58
+        self.size = 4
+        self.w = self.size
+        self.h = self.size
+        self.squares = self.size * self.size
+        self.score = 0
+        self.action_space, self.observation_space = make_spaces()
+        if engine is None:
+            from .batched import Batched2048
+            engine = Batched2048(1, device=device, seed=int.from_bytes(os.urandom(8), "little"))
+        self._eng = engine
+        self._slot = 0          # next spawn slot of the current transaction
+        self.set_illegal_move_reward(0.0)
+        self.set_max_tile(None)
+        self.grid_size = GRID_SIZE
+        self.render_mode = render_mode
+
+    # ------------------------------------------------------------------ configuration
+    def set_illegal_move_reward(self, reward):
+        """game2048_env.py:61-67."""
+        self.illegal_move_reward = reward
+        self.reward_range = (self.illegal_move_reward, float(2 ** self.squares))
+        self._eng.set_illegal_move_reward(float(reward))
+
+    def set_max_tile(self, max_tile):
+        """game2048_env.py:69-73."""
+        assert max_tile is None or isinstance(max_tile, int)
+        self.max_tile = max_tile
+        self._eng.set_max_tile(max_tile)
+
+    # ------------------------------------------------------------------ gym interface
+    def step(self, action):
+        """game2048_env.py:76-100."""
+        res = self._eng.step_numpy(np.array([int(action)]), auto_reset=False)
+        illegal = bool(res["illegal"][0])
+        info = {"illegal_move": illegal}
+        if illegal:
+            reward = self.illegal_move_reward
+            self._slot = 0
+        else:
+            reward = float(res["reward"][0])
+            self.score += reward
+            self._slot = 1
+        info["highest"] = self.highest()
+        return self._obs(), reward, bool(res["terminated"][0]), False, info
+
+    def reset(self, seed=None, options=None):
+        """game2048_env.py:102-111."""
+        if seed is not None:
+            self._eng.seed(int(seed))
+            self._slot = 0
+        self._eng.reset(first_slot=self._slot, new_transaction=False)
+        self._slot += 2
+        self.score = 0
+        return self._obs(), {}
+
+    def render(self, mode=None):
+        """game2048_env.py:113-163."""
+        if mode is None:
+            mode = self.render_mode or "human"
+        return render_board(self.Matrix, self.score, mode)
+
+    def close(self):
+        pass
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ------------------------------------------------------------------ board access
+    def _obs(self):
+        return self._eng.onehot_numpy()[0].astype(int)
+
+    @property
+    def Matrix(self):
+        """game2048_env.py:104 -- int64 (4,4) tile values (a host copy of the device board)."""
+        return _exp_to_values(self._eng.get_boards()[0])
+
+    @Matrix.setter
+    def Matrix(self, new_board):
+        self._eng.set_boards(_values_to_exp(np.asarray(new_board).reshape(1, 4, 4)))
+
+    def get(self, x, y):
+        """game2048_env.py:178-180."""
+        return self.Matrix[x, y]
+
+    def set(self, x, y, val):
+        """game2048_env.py:182-184."""
+        m = self.Matrix
+        m[x, y] = val
+        self.Matrix = m
+
+    def empties(self):
+        """game2048_env.py:186-188."""
+        return np.argwhere(self.Matrix == 0)
+
+    def highest(self):
+        """game2048_env.py:190-192."""
+        return np.max(self.Matrix)
+
+    def get_board(self):
+        """game2048_env.py:282-284."""
+        return self.Matrix
+
+    def set_board(self, new_board):
+        """game2048_env.py:286-288."""
+        self.Matrix = new_board
+
+    # ------------------------------------------------------------------ game primitives
+    def add_tile(self):
+        """game2048_env.py:166-176: one spawn from the next slot of the current transaction."""
+        assert (self.Matrix == 0).any(), "No empty cell found"
+        self._eng.add_tile(self._slot)
+        self._slot += 1
+
+    def move(self, direction, trial=False):
+        """game2048_env.py:194-241."""
+        score, legal = self._eng.move_numpy(np.array([int(direction)]), trial=bool(trial))
+        if not legal[0]:
+            raise IllegalMove
+        return int(score[0])
+
+    def shift(self, row):
+        """game2048_env.py:243-260 (runs as a left move of a scratch board holding ``row``)."""
+        saved = self._eng.get_boards()
+        try:
+            board = np.zeros((1, 4, 4), np.uint8)
+            board[0, 0] = _values_to_exp(row)
+            self._eng.set_boards(board)
+            score, _ = self._eng.move_numpy(np.array([3]), trial=False)
+            out = _exp_to_values(self._eng.get_boards()[0, 0])
+        finally:
+            self._eng.set_boards(saved)
+        return [int(v) for v in out], int(score[0])
+
+    def isend(self):
+        """game2048_env.py:262-280."""
+        return bool(self._eng.isend_numpy()[0])

@@ -1,0 +1,177 @@
+/*
+ * g2048.h -- C ABI of the MI355X-native batched 2048 environment (libg2048_hip.so).
+ *
+ * The reference (rgal/gym-2048) has no FFI layer: its boundary is the Gymnasium Python API of
+ * Game2048Env (/root/reference/env/envs/game2048_env.py, cited below as game2048_env.py:LINE).
+ * This header is the boundary a reference-side binding would call instead of running the Python
+ * body of those methods; each entry point names the reference method it replaces.  INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative G2048_ERR_* code; the message of the last
+ *    failure on the calling thread is g2048_last_error().  No C++ exception crosses the ABI.
+ *  - The engine owns the per-board device state (boards, episodic score, episode bookkeeping).
+ *    The CALLER owns every I/O buffer and passes raw device pointers (e.g. torch.Tensor.data_ptr());
+ *    no allocation and no host synchronisation happens inside reset/step/rollout/onehot.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued on
+ *    it; results are ready when the stream reaches that point.
+ *  - A board is 16 x uint8 exponents, row-major: 0 = empty, k = tile 2^k (reference: int64 tile
+ *    values in a 4x4 ndarray, game2048_env.py:104).  Actions: 0 up, 1 right, 2 down, 3 left
+ *    (game2048_env.py:196); only the low two bits of an action are used.
+ *  - An engine is not thread-safe; use one engine per device per process.
+ *
+ * Randomness: the "spawn stream" (oracle/g2048_oracle.h has the same text and is the checker)
+ *    word(seed, t, board, slot) = Philox4x32-10(ctr = (t_lo, t_hi, board, slot >> 2),
+ *                                               key = (seed_lo, seed_hi))[slot & 3]
+ *  t     transaction counter: 0 for the reset after seeding, +1 for every step;
+ *  board global board index = board_offset + local index (so results do not depend on how the
+ *        batch is sharded over GPUs);
+ *  slot  0 for the step's spawn, then the two spawns of a reset that follows in the same transaction.
+ *  A spawn with word w on a board with n empty cells puts 2 if (w & 0xffff) <= 58982 else 4 into
+ *  the k-th empty cell (row-major), k = (w * n) >> 32   (game2048_env.py:166-176).
+ */
+#ifndef G2048_H
+#define G2048_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2048_OK 0
+#define G2048_ERR_INVALID (-1) /* bad argument */
+#define G2048_ERR_HIP (-2)     /* a HIP runtime call failed (includes "no GPU") */
+#define G2048_ERR_NOMEM (-3)
+
+/* dtype codes for actions */
+#define G2048_ACT_RANDOM 0 /* no buffer: synthetic uniform policy, action = word(seed,t,board,3) >> 30 */
+#define G2048_ACT_U8 1
+#define G2048_ACT_I32 2
+#define G2048_ACT_I64 3 /* what torch.argmax / multinomial produce */
+
+/* dtype codes for the one-hot observation */
+#define G2048_OBS_U8 0
+#define G2048_OBS_F16 1
+#define G2048_OBS_F32 2
+
+typedef struct g2048_engine g2048_engine;
+
+/* Per-step I/O buffers, all device pointers of n elements; NULL = not wanted.
+ * Replaces the tuple returned by Game2048Env.step (game2048_env.py:100). */
+typedef struct {
+    const void *actions;     /* [n] of action_dtype; ignored for G2048_ACT_RANDOM */
+    int32_t action_dtype;    /* G2048_ACT_* */
+    float *reward;           /* [n] merge score of the move, or illegal_move_reward (:90,:95) */
+    uint8_t *terminated;     /* [n] (:89,:94) */
+    uint8_t *illegal;        /* [n] info['illegal_move'] (:79-81,:93) */
+    uint8_t *highest;        /* [n] log2(info['highest']) (:97), of the board BEFORE an auto-reset */
+    uint8_t *terminal_boards;/* [n][16] written only where terminated: the episode's last board */
+} g2048_step_io;
+
+/* Aggregate episode statistics (whole life of the engine since create/seed). */
+typedef struct {
+    uint64_t episodes;       /* finished episodes */
+    int64_t score_sum;       /* sum of their final merge scores (game2048_env.py:86) */
+    int64_t length_sum;      /* sum of their lengths in steps */
+    int32_t max_score;       /* best final score */
+    uint32_t max_exp;        /* highest exponent currently on any board */
+} g2048_stats;
+
+const char *g2048_last_error(void);
+/* Library / ABI version, bumped on any signature change. */
+int g2048_abi_version(void);
+
+/* Game2048Env.__init__ (game2048_env.py:38-58) for n_boards boards on HIP device `device`.
+ * Boards are all-empty until g2048_reset.  board_offset = global index of local board 0. */
+int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out);
+int g2048_destroy(g2048_engine *e);
+
+/* gym.Env.reset(seed=...) seeding half (game2048_env.py:103): restart the spawn stream, t = 0. */
+int g2048_seed(g2048_engine *e, uint64_t seed);
+int g2048_get_clock(const g2048_engine *e, uint64_t *t);
+int g2048_set_clock(g2048_engine *e, uint64_t t);
+uint64_t g2048_num_boards(const g2048_engine *e);
+
+/* set_illegal_move_reward (game2048_env.py:61-67) / set_max_tile (:69-73; max_exp = log2(max_tile),
+ * 0 = None). */
+int g2048_set_illegal_move_reward(g2048_engine *e, float reward);
+int g2048_set_max_tile(g2048_engine *e, int max_exp);
+
+/* Game2048Env.reset (game2048_env.py:102-111) for every board: zero board, score 0, two spawns.
+ * new_transaction != 0: t += 1 first (a reset that is not the first use of the stream);
+ * first_slot: slot of the first spawn (0 unless continuing a transaction that already spawned).
+ * mask: optional device uint8[n]; when non-NULL only boards with mask != 0 are reset. */
+int g2048_reset(g2048_engine *e, int new_transaction, uint32_t first_slot, const uint8_t *mask, void *stream);
+
+/* Game2048Env.step (game2048_env.py:76-100) for every board: t += 1, move, score, spawn, done.
+ * auto_reset != 0 additionally performs the caller's `if terminated: env.reset()` in the same
+ * launch (slots 1,2 after a legal move, 0,1 after an illegal one). */
+int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *stream);
+
+/* k consecutive g2048_step launches without returning to the caller.  Buffers of step j are the
+ * io pointers advanced by j * stride elements (stride = 0 reuses the same buffers, stride = n
+ * walks [k][n] rollout buffers). */
+int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
+                  void *stream);
+
+/* ONE launch that plays k steps of the synthetic random policy with boards held in registers
+ * (auto-reset on).  Writes only the final state and the episode bookkeeping. */
+int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream);
+
+/* Game2048Env.move alone (game2048_env.py:194-241) for every board: no spawn, no score update, no
+ * clock tick.  score_out int32[n] = merge score (0 where illegal); legal_out uint8[n] = 0 where the
+ * reference raises IllegalMove (:238-239).  trial != 0 leaves the boards untouched (:224,:236).
+ * action_dtype must name a buffer (G2048_ACT_U8/I32/I64). */
+int g2048_move(g2048_engine *e, const void *actions, int32_t action_dtype, int trial, int32_t *score_out,
+               uint8_t *legal_out, void *stream);
+
+/* Game2048Env.isend (game2048_env.py:262-280, uses the engine's max_tile) and highest (:190-192, as
+ * an exponent) for every board; either output may be NULL. */
+int g2048_query(const g2048_engine *e, uint8_t *isend_out, uint8_t *highest_out, void *stream);
+
+/* Game2048Env.add_tile (game2048_env.py:166-176): one spawn from slot `slot` of the current
+ * transaction on every board that has an empty cell. */
+int g2048_add_tile(g2048_engine *e, uint32_t slot, void *stream);
+
+/* Fill out[j][i] (uint8, j < k_steps, i < n) with the synthetic policy's action of transaction
+ * t_first + j for board i -- the same values G2048_ACT_RANDOM would use at those transactions. */
+int g2048_fill_random_actions(const g2048_engine *e, uint64_t t_first, uint32_t k_steps, uint8_t *out, void *stream);
+
+/* stack() (game2048_env.py:17-32): out[n][16][4][4] of obs_dtype, channel c = (exponent == c). */
+int g2048_onehot(const g2048_engine *e, void *out, int32_t obs_dtype, void *stream);
+
+/* get_board / set_board (game2048_env.py:282-288) for the whole batch; `buf` is [n][16] uint8
+ * exponents in host or device memory (hipMemcpyDefault). set_boards does not touch the scores. */
+int g2048_get_boards(const g2048_engine *e, uint8_t *buf, void *stream);
+int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream);
+
+/* Episodic merge score self.score (game2048_env.py:46,86,105): int32[n], host or device. */
+int g2048_get_scores(const g2048_engine *e, int32_t *buf, void *stream);
+int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream);
+
+/* Per-board record of the most recently finished episode (written when a step terminates):
+ * last_score int32[n], last_len int32[n] (steps), ep_count uint32[n].  NULL = skip. */
+int g2048_get_episode_records(const g2048_engine *e, int32_t *last_score, int32_t *last_len, uint32_t *ep_count,
+                              void *stream);
+
+/* Raw device pointers of the engine-owned state for zero-copy views (boards: uint8[n][16],
+ * scores: int32[n], last_score: int32[n]).  Valid until g2048_destroy. */
+void *g2048_boards_ptr(const g2048_engine *e);
+void *g2048_scores_ptr(const g2048_engine *e);
+void *g2048_last_score_ptr(const g2048_engine *e);
+
+/* Reduce the episode bookkeeping on the device and copy the result to *out (synchronises `stream`). */
+int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
+
+/* Checkpoint / resume of the complete engine state (boards, scores, episode bookkeeping, seed,
+ * clock, configuration) as one host blob of g2048_state_bytes() bytes.  The reference checkpoints
+ * only models; its env state hooks are get_board/set_board (game2048_env.py:282-288). */
+uint64_t g2048_state_bytes(const g2048_engine *e);
+int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream);
+int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+"""CPU ORACLE package -- TEST INFRASTRUCTURE ONLY (see g2048_oracle.h / cpu_ref.py).
+
+``load()`` returns a ctypes handle on ``libg2048_oracle.so`` (built by ``make -C oracle`` or by
+``__graft_entry__.build()``), with argtypes set.  ``OracleBatch`` is a numpy-backed driver with
+the same state/outputs as the device engine, used by the parity tests as the checker.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libg2048_oracle.so")
+_lib = None
+
+
+class _Batch(C.Structure):
+    _fields_ = [
+        ("boards", C.c_void_p), ("score", C.c_void_p), ("ep_start", C.c_void_p),
+        ("actions", C.c_void_p),
+        ("reward", C.c_void_p), ("terminated", C.c_void_p), ("illegal", C.c_void_p),
+        ("highest", C.c_void_p), ("terminal_boards", C.c_void_p), ("last_score", C.c_void_p),
+        ("last_len", C.c_void_p), ("ep_count", C.c_void_p),
+    ]
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("g2048_oracle.c", "g2048_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libg2048_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    u32, u64, i64p = C.c_uint32, C.c_uint64, C.POINTER(C.c_int64)
+    lib.g2048o_philox4x32_10.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    lib.g2048o_spawn_word.argtypes = [u64, u64, u32, u32]
+    lib.g2048o_spawn_word.restype = u32
+    lib.g2048o_random_action.argtypes = [u64, u64, u32]
+    lib.g2048o_random_action.restype = C.c_uint8
+    lib.g2048o_shift.argtypes = [i64p, i64p]
+    lib.g2048o_shift.restype = C.c_int64
+    lib.g2048o_move.argtypes = [i64p, C.c_int, C.c_int, i64p]
+    lib.g2048o_move.restype = C.c_int
+    lib.g2048o_highest.argtypes = [i64p]
+    lib.g2048o_highest.restype = C.c_int64
+    lib.g2048o_isend.argtypes = [i64p, C.c_int64]
+    lib.g2048o_isend.restype = C.c_int
+    lib.g2048o_add_tile.argtypes = [i64p, u32]
+    lib.g2048o_add_tile.restype = C.c_int
+    lib.g2048o_stack.argtypes = [i64p, i64p]
+    lib.g2048o_reset_batch.argtypes = [C.POINTER(_Batch), u64, u64, u64, u64, u32, C.c_int]
+    lib.g2048o_step_batch.argtypes = [C.POINTER(_Batch), u64, u64, u64, u64, C.c_float, C.c_int, C.c_int, C.c_int]
+    lib.g2048o_onehot_batch.argtypes = [C.c_void_p, u64, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class OracleBatch:
+    """N boards stepped by the C oracle, in the device data layout (the parity checker)."""
+
+    def __init__(self, n: int, seed: int = 0, board_offset: int = 0, threads: int = 1):
+        self.lib = load()
+        self.n, self.seed, self.board_offset, self.threads = n, seed, board_offset, threads
+        self.t = 0
+        self.fresh = True
+        self.illegal_move_reward = 0.0
+        self.max_exp = 0
+        self.boards = np.zeros((n, 16), np.uint8)
+        self.score = np.zeros(n, np.int32)
+        self.ep_start = np.zeros(n, np.uint32)
+        self.reward = np.zeros(n, np.float32)
+        self.terminated = np.zeros(n, np.uint8)
+        self.illegal = np.zeros(n, np.uint8)
+        self.highest = np.zeros(n, np.uint8)
+        self.terminal_boards = np.zeros((n, 16), np.uint8)
+        self.last_score = np.zeros(n, np.int32)
+        self.last_len = np.zeros(n, np.int32)
+        self.ep_count = np.zeros(n, np.uint32)
+
+    def _batch(self, actions=None):
+        return _Batch(_ptr(self.boards), _ptr(self.score), _ptr(self.ep_start), _ptr(actions),
+                      _ptr(self.reward), _ptr(self.terminated), _ptr(self.illegal), _ptr(self.highest),
+                      _ptr(self.terminal_boards), _ptr(self.last_score), _ptr(self.last_len),
+                      _ptr(self.ep_count))
+
+    def seed_(self, seed: int):
+        self.seed, self.t, self.fresh = seed, 0, True
+
+    def reset(self, first_slot: int = 0, new_transaction=None):
+        if new_transaction is None:
+            new_transaction = not self.fresh
+        if new_transaction:
+            self.t += 1
+        self.fresh = False
+        b = self._batch()
+        self.lib.g2048o_reset_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset, first_slot,
+                                    self.threads)
+
+    def step(self, actions=None, auto_reset: bool = True):
+        """actions: uint8[n] or None for the synthetic random policy."""
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.uint8)
+            assert actions.shape == (self.n,)
+        self.t += 1
+        self.fresh = False
+        b = self._batch(actions)
+        self.lib.g2048o_step_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset,
+                                   self.illegal_move_reward, self.max_exp, int(auto_reset), self.threads)
+
+    def onehot(self):
+        out = np.zeros((self.n, 16, 4, 4), np.uint8)
+        self.lib.g2048o_onehot_batch(_ptr(self.boards), self.n, _ptr(out))
+        return out

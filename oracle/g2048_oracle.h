@@ -1,0 +1,133 @@
+/*
+ * g2048_oracle.h -- CPU ORACLE for the batched 2048 step/reset path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call anything in oracle/.  The product
+ * (gym-2048_amd/) never links or imports it and has no CPU fallback.
+ *
+ * It is a plain-C restatement of the reference algorithm in
+ *   /root/reference/env/envs/game2048_env.py   (cited below as game2048_env.py:LINE)
+ * working, like the reference, on int64 *tile values* (2, 4, 8, ...), plus a thin batch driver
+ * that speaks the device data layout (uint8 exponent boards, 16 B per board) so the HIP
+ * kernels can be compared with it byte for byte.
+ *
+ * Parity pin: the reference's RNG is gymnasium's np_random (numpy PCG64), a third-party,
+ * unpinned dependency that no reference test pins.  Bit-exactness is
+ * therefore defined through RNG injection: tests/golden/make_golden.py imports the unmodified
+ * reference, replaces env.np_random with the Philox "spawn stream" defined here, and records
+ * trajectories.  This oracle is pinned against those recordings and against every known-answer
+ * value in the reference's own test file (test_game2048_env.py) and data/test_data.csv.
+ */
+#ifndef G2048_ORACLE_H
+#define G2048_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ RNG: the spawn stream */
+
+/* Philox4x32-10 (Salmon et al., SC'11; same constants as rocrand_philox4x32_10.h:62-65). */
+void g2048o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* word(seed, t, board, slot) = Philox4x32-10(ctr = (t_lo, t_hi, board, slot >> 2),
+ *                                            key = (seed_lo, seed_hi))[slot & 3]
+ * t     = transaction counter of the env (0 = the reset after seeding, +1 per step() call)
+ * board = global board index (invariant to batch size / sharding)
+ * slot  = spawn slot inside the transaction (0 = the step's spawn, then the reset's two) */
+uint32_t g2048o_spawn_word(uint64_t seed, uint64_t t, uint32_t board, uint32_t slot);
+
+/* Synthetic uniform-random policy used by the benchmark rollouts:
+ * action(seed, t, board) = word(seed, t, board, 3) >> 30. */
+uint8_t g2048o_random_action(uint64_t seed, uint64_t t, uint32_t board);
+
+/* The two quantities add_tile needs from one 32-bit word (game2048_env.py:168-175):
+ *   value:    2 if (w & 0xffff) / 65536.0 < 0.9 else 4     (<=> (w & 0xffff) <= 58982)
+ *   position: the k-th empty cell in row-major order, k = (w * n_empty) >> 32            */
+int64_t g2048o_spawn_value(uint32_t w);
+uint32_t g2048o_spawn_rank(uint32_t w, uint32_t n_empty);
+
+/* ------------------------------------------------ reference functions, on int64 tile values */
+
+/* game2048_env.py:243-260  Game2048Env.shift -- returns the merge score. */
+int64_t g2048o_shift(const int64_t row[4], int64_t combined_row[4]);
+
+/* game2048_env.py:194-241  Game2048Env.move.  Returns 1 if the board changed, 0 where the
+ * reference raises IllegalMove.  trial != 0 leaves M untouched.  *move_score gets the sum. */
+int g2048o_move(int64_t M[16], int direction, int trial, int64_t *move_score);
+
+/* game2048_env.py:190-192  Game2048Env.highest */
+int64_t g2048o_highest(const int64_t M[16]);
+
+/* game2048_env.py:262-280  Game2048Env.isend; max_tile == 0 stands for None. */
+int g2048o_isend(const int64_t M[16], int64_t max_tile);
+
+/* game2048_env.py:166-176  Game2048Env.add_tile with the injected spawn word.
+ * Returns the flat index of the new tile, or -1 where the reference asserts (board full). */
+int g2048o_add_tile(int64_t M[16], uint32_t w);
+
+/* game2048_env.py:17-32  stack(): (4,4) -> (16,4,4) one-hot, int64 {0,1}. */
+void g2048o_stack(const int64_t M[16], int64_t out[256]);
+
+/* ------------------------------------------------------------- single env (reference shape) */
+
+typedef struct {
+    int64_t M[16];              /* game2048_env.py:104  self.Matrix (row-major) */
+    double score;               /* game2048_env.py:46,86,105 */
+    double illegal_move_reward; /* game2048_env.py:61-67 */
+    int64_t max_tile;           /* game2048_env.py:69-73, 0 = None */
+    uint64_t seed, t;           /* spawn stream position */
+    uint32_t board, slot;
+} g2048o_env;
+
+void g2048o_env_init(g2048o_env *e, uint64_t seed, uint32_t board);
+/* game2048_env.py:102-111; reseed != 0 restarts the stream (t = 0, slot = 0). */
+void g2048o_env_reset(g2048o_env *e, int reseed, uint64_t seed);
+/* game2048_env.py:76-100; returns terminated. */
+int g2048o_env_step(g2048o_env *e, int action, double *reward, int *illegal, int64_t *highest);
+
+/* ------------------------------------------- batch driver in the device layout (exponents) */
+
+/* Convert between uint8 exponent boards (0 = empty, k = tile 2^k) and int64 tile values. */
+void g2048o_exp_to_values(const uint8_t b[16], int64_t M[16]);
+void g2048o_values_to_exp(const int64_t M[16], uint8_t b[16]);
+
+typedef struct {
+    /* state, in/out */
+    uint8_t *boards;    /* [n][16] */
+    int32_t *score;     /* [n] episodic merge score (game2048_env.py:86) */
+    uint32_t *ep_start; /* [n] low 32 bits of the transaction at which the episode began */
+    /* inputs */
+    const uint8_t *actions; /* [n], NULL => synthetic random policy g2048o_random_action */
+    /* per-step outputs (any may be NULL) */
+    float *reward;           /* [n] */
+    uint8_t *terminated;     /* [n] */
+    uint8_t *illegal;        /* [n] info['illegal_move'] */
+    uint8_t *highest;        /* [n] exponent of info['highest'] (board before any auto-reset) */
+    uint8_t *terminal_boards;/* [n][16] written for terminated boards only */
+    int32_t *last_score;     /* [n] written for terminated boards only */
+    int32_t *last_len;       /* [n] written for terminated boards only */
+    uint32_t *ep_count;      /* [n] += 1 for terminated boards */
+} g2048o_batch;
+
+/* reset every board: zero, score 0, two spawns from slots first_slot, first_slot+1 of
+ * transaction t (game2048_env.py:102-111). */
+void g2048o_reset_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t,
+                        uint64_t board_offset, uint32_t first_slot, int threads);
+
+/* one step of every board at transaction t (game2048_env.py:76-100), followed -- when
+ * auto_reset != 0 -- by `if terminated: env.reset()` for the boards that ended.
+ * max_exp: 0 = no max_tile, else log2(max_tile). */
+void g2048o_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t,
+                       uint64_t board_offset, float illegal_move_reward, int max_exp,
+                       int auto_reset, int threads);
+
+/* (n,16) exponents -> (n,16,4,4) one-hot uint8 (game2048_env.py:17-32). */
+void g2048o_onehot_batch(const uint8_t *boards, uint64_t n, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

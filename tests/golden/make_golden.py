@@ -1,0 +1,461 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in tests/golden/ FROM THE IMPORTED REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py [--validate-steps 1000000]
+
+What it does
+------------
+1. Imports the *unmodified* reference package ``env`` from /root/reference.  ``gymnasium`` is not
+   installed in this image, so a minimal in-memory stand-in for the three things the env touches
+   (``gym.Env`` with the seeding ``reset``/``np_random`` property, ``spaces.Discrete/Box`` and
+   ``register``) is put into ``sys.modules`` first.  The stand-in is used only by
+   this generator; nothing of the reference or of the stand-in is written to the repo.
+2. Replaces ``env.np_random`` by ``oracle.cpu_ref.SpawnStream`` (RNG injection) and records what
+   the reference computes: shift/move/isend/stack known answers and multi-step trajectories of the
+   loop ``obs, r, term, _, info = env.step(a); if term: env.reset()``.
+3. Converts the reference's own fixture ``data/test_data.csv`` (848 recorded transitions) to npz.
+4. Cross-checks the C oracle and the Python oracle against the reference over ``--validate-steps``
+   steps and writes the report to ``VALIDATION.txt``.
+
+The outputs are *data* (inputs + expected outputs); no reference source text is stored.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import itertools
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import OracleBatch, load as load_oracle  # noqa: E402
+from oracle.cpu_ref import RefEnv, SpawnStream, random_action, values_to_exp  # noqa: E402
+
+
+def install_gymnasium_stand_in():
+    gym = types.ModuleType("gymnasium")
+
+    class Env:
+        _np_random = None
+
+        def reset(self, *, seed=None, options=None):
+            if seed is not None:
+                self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+        @property
+        def np_random(self):
+            if self._np_random is None:
+                self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence()))
+            return self._np_random
+
+        @np_random.setter
+        def np_random(self, value):
+            self._np_random = value
+
+    spaces = types.ModuleType("gymnasium.spaces")
+
+    class Discrete:
+        def __init__(self, n):
+            self.n = n
+
+    class Box:
+        def __init__(self, low, high, shape, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    spaces.Discrete, spaces.Box = Discrete, Box
+    envs = types.ModuleType("gymnasium.envs")
+    registration = types.ModuleType("gymnasium.envs.registration")
+    registration.register = lambda **kw: None
+    envs.registration = registration
+    gym.Env, gym.spaces, gym.envs = Env, spaces, envs
+    sys.modules.update({"gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.envs": envs,
+                        "gymnasium.envs.registration": registration})
+
+
+def import_reference():
+    install_gymnasium_stand_in()
+    sys.path.insert(0, REFERENCE)
+    import env.envs.game2048_env as ref  # noqa
+    return ref
+
+
+class RefDriver:
+    """The unmodified reference env + injected spawn stream + the canonical driving loop."""
+
+    def __init__(self, ref, seed, board=0, illegal_move_reward=None, max_tile=None):
+        self.ref = ref
+        self.env = ref.Game2048Env()
+        if illegal_move_reward is not None:
+            self.env.set_illegal_move_reward(illegal_move_reward)
+        if max_tile is not None:
+            self.env.set_max_tile(max_tile)
+        self.stream = SpawnStream(self.env, seed, board)
+        self.env.np_random = self.stream
+        self.env.reset()
+
+    def legal_actions(self):
+        out = []
+        for d in range(4):
+            try:
+                self.env.move(d, trial=True)
+                out.append(d)
+            except self.ref.IllegalMove:
+                pass
+        return out
+
+    def step(self, action, auto_reset=True):
+        self.stream.begin_step()
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        assert truncated is False
+        rec = dict(reward=reward, terminated=bool(terminated), illegal=bool(info["illegal_move"]),
+                   highest=int(info["highest"]), terminal_board=self.env.get_board().copy(),
+                   terminal_score=self.env.score, obs=obs)
+        if terminated and auto_reset:
+            self.env.reset()
+        rec["board"] = self.env.get_board().copy()
+        rec["score"] = self.env.score
+        return rec
+
+
+# ------------------------------------------------------------------------------------- pieces
+
+
+def gen_shift_table(ref):
+    """Exhaustive shift() table over exponents 0..17 (104 976 rows)."""
+    e = ref.Game2048Env()
+    out = np.zeros((18 ** 4, 4), np.uint8)
+    score = np.zeros(18 ** 4, np.int32)
+    for i, exps in enumerate(itertools.product(range(18), repeat=4)):
+        row = [0 if x == 0 else 1 << x for x in exps]
+        new, ms = e.shift(row)
+        out[i] = values_to_exp(new)
+        score[i] = ms
+    return dict(out=out, score=score)
+
+
+def random_boards(rng, n, max_exp=11):
+    """Boards with varied fill levels and lots of equal neighbours (exponents)."""
+    boards = np.zeros((n, 16), np.uint8)
+    for i in range(n):
+        fill = rng.integers(1, 17)
+        top = rng.integers(1, max_exp + 1)
+        cells = rng.choice(16, size=fill, replace=False)
+        boards[i, cells] = rng.integers(1, top + 1, size=fill)
+    return boards
+
+
+def gen_move_table(ref, rng, n=1536):
+    e = ref.Game2048Env()
+    boards = random_boards(rng, n)
+    boards[:64] = random_boards(rng, 64, max_exp=17)           # very high tiles
+    boards[64:128] = rng.integers(1, 3, size=(64, 16))         # full boards, many merges
+    new = np.zeros((n, 4, 16), np.uint8)
+    score = np.zeros((n, 4), np.int32)
+    legal = np.zeros((n, 4), np.uint8)
+    end = np.zeros(n, np.uint8)
+    highest = np.zeros(n, np.uint8)
+    for i in range(n):
+        vals = np.where(boards[i] > 0, 1 << boards[i].astype(np.int64), 0).reshape(4, 4)
+        e.set_board(vals.copy())
+        end[i] = e.isend()
+        highest[i] = values_to_exp(e.highest())
+        for d in range(4):
+            e.set_board(vals.copy())
+            try:
+                score[i, d] = e.move(d)
+                legal[i, d] = 1
+            except ref.IllegalMove:
+                pass
+            new[i, d] = values_to_exp(e.get_board()).reshape(16)
+    return dict(boards=boards, new=new, score=score, legal=legal, isend=end, highest=highest)
+
+
+def gen_isend_table(ref, rng, n=512):
+    """Full boards (the only place isend's trial moves matter) + max_tile cases."""
+    e = ref.Game2048Env()
+    boards = np.zeros((n, 16), np.uint8)
+    for i in range(n):
+        if i % 2 == 0:   # checkerboard-ish full boards with a few forced equal neighbours
+            b = np.array([[((r + c) % 2) + 1 + 2 * ((r * 4 + c) % 3) for c in range(4)] for r in range(4)])
+            b = b.reshape(16)
+            for _ in range(rng.integers(0, 3)):
+                j = rng.integers(0, 16)
+                b[j] = b[(j + rng.choice([1, 4])) % 16]
+            boards[i] = b
+        else:
+            boards[i] = rng.integers(1, 6, size=16)
+    max_exp = rng.integers(0, 12, size=n).astype(np.uint8)      # 0 = no max_tile
+    boards[-32:, 3] = 0                                         # some with an empty cell
+    end = np.zeros(n, np.uint8)
+    for i in range(n):
+        e.set_max_tile(None if max_exp[i] == 0 else int(1 << int(max_exp[i])))
+        e.set_board(np.where(boards[i] > 0, 1 << boards[i].astype(np.int64), 0).reshape(4, 4))
+        end[i] = e.isend()
+    return dict(boards=boards, max_exp=max_exp, isend=end)
+
+
+def gen_stack_table(ref, rng, n=64):
+    boards = random_boards(rng, n, max_exp=15)
+    boards[0] = np.arange(16)                    # every layer once
+    boards[1] = np.arange(2, 18)                 # includes 2^16 and 2^17: all-zero columns
+    boards[2] = 0
+    out = np.zeros((n, 16, 4, 4), np.uint8)
+    for i in range(n):
+        vals = np.where(boards[i] > 0, 1 << boards[i].astype(np.int64), 0).reshape(4, 4)
+        s = ref.stack(vals)
+        assert s.shape == (16, 4, 4) and set(np.unique(s)) <= {0, 1}
+        out[i] = s
+    return dict(boards=boards, onehot=out)
+
+
+def greedy_action(legal, random_a, t):
+    """'greedy' test policy: the random action on every 41st step (may be illegal -> episode ends
+    with the illegal-move reward), the random action if legal on every 7th, else the first legal
+    of left, down, right, up.  Gives long episodes, big tiles and full-board endings."""
+    if t % 41 == 0 or (t % 7 == 0 and random_a in legal):
+        return random_a
+    return next((d for d in (3, 2, 1, 0) if d in legal), random_a)
+
+
+def gen_trajectories(ref, name, seed, n_boards, n_steps, policy, board_offset=0,
+                     illegal_move_reward=None, max_tile=None, auto_reset=True):
+    """policy: 'random' (the synthetic benchmark policy) or 'greedy' (see greedy_action)."""
+    shape = (n_boards, n_steps)
+    out = dict(actions=np.zeros(shape, np.uint8), reward=np.zeros(shape, np.float32),
+               terminated=np.zeros(shape, np.uint8), illegal=np.zeros(shape, np.uint8),
+               highest=np.zeros(shape, np.uint8), score=np.zeros(shape, np.int32),
+               boards=np.zeros(shape + (16,), np.uint8), terminal_boards=np.zeros(shape + (16,), np.uint8),
+               terminal_score=np.zeros(shape, np.int32), initial_boards=np.zeros((n_boards, 16), np.uint8))
+    for b in range(n_boards):
+        drv = RefDriver(ref, seed, board_offset + b, illegal_move_reward, max_tile)
+        out["initial_boards"][b] = values_to_exp(drv.env.get_board()).reshape(16)
+        for s in range(n_steps):
+            t = s + 1
+            a = random_action(seed, t, board_offset + b)
+            if policy == "greedy":
+                a = greedy_action(drv.legal_actions(), a, t)
+            rec = drv.step(a, auto_reset)
+            out["actions"][b, s] = a
+            out["reward"][b, s] = rec["reward"]
+            out["terminated"][b, s] = rec["terminated"]
+            out["illegal"][b, s] = rec["illegal"]
+            out["highest"][b, s] = values_to_exp(rec["highest"])
+            out["score"][b, s] = rec["score"]
+            out["boards"][b, s] = values_to_exp(rec["board"]).reshape(16)
+            out["terminal_boards"][b, s] = values_to_exp(rec["terminal_board"]).reshape(16)
+            out["terminal_score"][b, s] = rec["terminal_score"]
+    out["meta"] = np.array([seed, board_offset, n_boards, n_steps,
+                            0 if max_tile is None else int(np.log2(max_tile)), int(auto_reset)], np.int64)
+    out["illegal_move_reward"] = np.array([0.0 if illegal_move_reward is None else illegal_move_reward],
+                                          np.float32)
+    out["name"] = np.array(name)
+    return out
+
+
+def gen_reference_test_kats(ref):
+    """Re-capture, by calling the reference, the values its own unit tests pin
+    (test_game2048_env.py:13-34 shift rows, :40-98 move board, :113-151 isend, :165-217 step)."""
+    e = ref.Game2048Env()
+    rows = [[0, 0, 0, 0], [0, 2, 0, 0], [0, 2, 0, 4], [2, 4, 8, 16], [2, 2, 8, 0], [4, 2, 2, 4],
+            [2, 2, 2, 8], [2, 8, 4, 4], [2, 2, 4, 4], [2, 4, 4, 4], [4, 4, 4, 4], [0, 2, 2, 8]]
+    shift_out = [e.shift(r) for r in rows]
+    board = [[0, 2, 0, 4], [2, 2, 8, 0], [2, 2, 2, 8], [2, 2, 4, 4]]
+    move_out = []
+    for d in range(4):
+        e.set_board(np.array(board))
+        sc = e.move(d)
+        move_out.append((sc, e.get_board().copy()))
+    # repeat-move illegal + follow-on move (test_game2048_env.py:89-98)
+    repeat_illegal = False
+    try:
+        e.move(3)
+    except ref.IllegalMove:
+        repeat_illegal = True
+    follow_score = e.move(2)
+    follow_board = e.get_board().copy()
+    # step KATs
+    e2 = ref.Game2048Env()
+    e2.np_random = SpawnStream(e2, 0)
+    e2.reset()
+    e2.set_board(np.array([[0, 0, 0, 0], [0, 0, 0, 0], [2, 0, 0, 0], [2, 0, 0, 0]]))
+    e2.np_random.begin_step()
+    _, r1, _, _, _ = e2.step(0)
+    e2.set_board(np.array([[0, 0, 0, 0], [0, 0, 0, 0], [4, 0, 0, 0], [4, 0, 0, 0]]))
+    e2.np_random.begin_step()
+    _, r2, _, _, _ = e2.step(0)
+    score_after = e2.score
+    e3 = ref.Game2048Env()
+    e3.set_illegal_move_reward(-1.0)
+    e3.np_random = SpawnStream(e3, 0)
+    e3.reset()
+    e3.set_board(np.array([[2, 4, 8, 16], [4, 8, 16, 2], [8, 16, 2, 4], [16, 2, 4, 8]]))
+    e3.np_random.begin_step()
+    _, r3, term3, _, info3 = e3.step(0)
+    return dict(
+        shift_rows=np.array(rows, np.int64), shift_out=np.array([o[0] for o in shift_out], np.int64),
+        shift_score=np.array([o[1] for o in shift_out], np.int64),
+        move_board=np.array(board, np.int64), move_score=np.array([m[0] for m in move_out], np.int64),
+        move_out=np.array([m[1] for m in move_out], np.int64),
+        repeat_illegal=np.array(repeat_illegal), follow_score=np.array(follow_score), follow_board=follow_board,
+        step_rewards=np.array([r1, r2]), step_score_after=np.array(score_after),
+        illegal_step=np.array([r3, float(term3), float(info3["illegal_move"])]),
+    )
+
+
+def gen_csv_fixture(ref):
+    """The reference's own fixture data/test_data.csv (848 human transitions), as arrays, plus what
+    the reference's move() computes for every row."""
+    raw = np.loadtxt(os.path.join(REFERENCE, "data", "test_data.csv"), delimiter=",", skiprows=1)
+    boards = raw[:, :16].astype(np.int64)
+    actions = raw[:, 16].astype(np.uint8)
+    rewards = raw[:, 17].astype(np.float32)
+    nxt = raw[:, 18:34].astype(np.int64)
+    done = raw[:, 34].astype(np.uint8)
+    e = ref.Game2048Env()
+    moved = np.zeros_like(boards)
+    ref_score = np.zeros(len(boards), np.int64)
+    for i in range(len(boards)):
+        e.set_board(boards[i].reshape(4, 4).copy())
+        ref_score[i] = e.move(int(actions[i]))
+        moved[i] = e.get_board().reshape(16)
+    assert np.array_equal(ref_score, rewards.astype(np.int64))
+    e.set_max_tile(2048)
+    e.set_board(nxt[-1].reshape(4, 4).copy())
+    last_isend_max2048 = e.isend()
+    return dict(boards=values_to_exp(boards), actions=actions, rewards=rewards, next_boards=values_to_exp(nxt),
+                done=done, moved=values_to_exp(moved), last_isend_max2048=np.array(last_isend_max2048))
+
+
+# ---------------------------------------------------------------------------------- validation
+
+
+def validate(ref, total_steps, report):
+    """C oracle + Python oracle vs the imported reference, step for step."""
+    lib = load_oracle()
+    n_boards = 64
+    per_board = max(1, total_steps // (n_boards * 3))
+    configs = [dict(seed=42, policy="random", irw=None, max_tile=None),
+               dict(seed=7, policy="greedy", irw=-1.0, max_tile=None),
+               dict(seed=2024, policy="greedy", irw=None, max_tile=256)]
+    t0 = time.time()
+    steps = 0
+    episodes = 0
+    for cfg in configs:
+        drivers = [RefDriver(ref, cfg["seed"], b, cfg["irw"], cfg["max_tile"]) for b in range(n_boards)]
+        ob = OracleBatch(n_boards, cfg["seed"])
+        ob.illegal_move_reward = 0.0 if cfg["irw"] is None else cfg["irw"]
+        ob.max_exp = 0 if cfg["max_tile"] is None else int(np.log2(cfg["max_tile"]))
+        ob.reset()
+        pys = [RefEnv(cfg["seed"], b) for b in range(n_boards)]
+        for p in pys:
+            p.illegal_move_reward = ob.illegal_move_reward
+            p.max_tile = cfg["max_tile"]
+            p.reset()
+        for b in range(n_boards):
+            assert np.array_equal(values_to_exp(drivers[b].env.get_board()).reshape(16), ob.boards[b])
+            assert list(drivers[b].env.get_board().reshape(16)) == pys[b].M
+        for s in range(per_board):
+            t = s + 1
+            acts = np.zeros(n_boards, np.uint8)
+            for b in range(n_boards):
+                a = random_action(cfg["seed"], t, b)
+                assert a == lib.g2048o_random_action(cfg["seed"], t, b)
+                if cfg["policy"] == "greedy":
+                    a = greedy_action(drivers[b].legal_actions(), a, t)
+                acts[b] = a
+            ob.step(acts)
+            for b in range(n_boards):
+                rec = drivers[b].step(int(acts[b]))
+                rw, term, ill, hi = pys[b].step(int(acts[b]))
+                if term:
+                    pys[b].reset()
+                # reference vs C oracle
+                assert rec["reward"] == ob.reward[b], (cfg, b, s)
+                assert rec["terminated"] == bool(ob.terminated[b])
+                assert rec["illegal"] == bool(ob.illegal[b])
+                assert values_to_exp(rec["highest"]) == ob.highest[b]
+                assert np.array_equal(values_to_exp(rec["board"]).reshape(16), ob.boards[b])
+                assert rec["score"] == ob.score[b]
+                if rec["terminated"]:
+                    assert np.array_equal(values_to_exp(rec["terminal_board"]).reshape(16), ob.terminal_boards[b])
+                    assert rec["terminal_score"] == ob.last_score[b]
+                    episodes += 1
+                # reference vs Python oracle
+                assert (rw, term, ill, hi) == (rec["reward"], rec["terminated"], rec["illegal"], rec["highest"])
+                assert list(rec["board"].reshape(16)) == pys[b].M
+                assert rec["score"] == pys[b].score
+            steps += n_boards
+    dt = time.time() - t0
+    report.append(f"validated {steps} env-steps ({episodes} episodes) of the imported reference against the C oracle "
+                  f"and the Python oracle: all boards/rewards/terminated/illegal/highest/scores identical "
+                  f"({dt:.0f} s)")
+
+
+def time_reference(ref, report):
+    """BASELINE config 1 for orientation: reference vs Python oracle, 1 core, 20 000 steps."""
+    n = 20000
+    drv = RefDriver(ref, 42)
+    acts = [random_action(42, t + 1, 0) for t in range(n)]
+    t0 = time.perf_counter()
+    for a in acts:
+        drv.step(a)
+    ref_rate = n / (time.perf_counter() - t0)
+    py = RefEnv(42, 0)
+    py.reset()
+    t0 = time.perf_counter()
+    for a in acts:
+        if py.step(a)[1]:
+            py.reset()
+    py_rate = n / (time.perf_counter() - t0)
+    report.append(f"reference Game2048Env.step (injected spawn stream, auto-reset loop): {ref_rate:.0f} steps/s; "
+                  f"oracle.cpu_ref.RefEnv: {py_rate:.0f} steps/s; ratio RefEnv/reference = {py_rate / ref_rate:.2f} "
+                  f"(1 core, this container)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--validate-steps", type=int, default=1_000_000)
+    args = ap.parse_args()
+    ref = import_reference()
+    rng = np.random.default_rng(20480)
+    report = []
+
+    def save(name, d):
+        path = os.path.join(HERE, name)
+        np.savez_compressed(path, **d)
+        h = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+        report.append(f"{name}: {os.path.getsize(path)} bytes sha256[:16]={h}")
+
+    save("shift_exhaustive.npz", gen_shift_table(ref))
+    save("move_table.npz", gen_move_table(ref, rng))
+    save("isend_table.npz", gen_isend_table(ref, rng))
+    save("stack_table.npz", gen_stack_table(ref, rng))
+    save("reference_test_kats.npz", gen_reference_test_kats(ref))
+    save("test_data_csv.npz", gen_csv_fixture(ref))
+    save("traj_random_seed42.npz", gen_trajectories(ref, "random", 42, 64, 256, "random"))
+    save("traj_random_offset.npz", gen_trajectories(ref, "random_offset", 42, 8, 128, "random",
+                                                    board_offset=(1 << 20) - 4))
+    save("traj_greedy_irw.npz", gen_trajectories(ref, "greedy_irw", 7, 16, 1024, "greedy",
+                                                 illegal_move_reward=-1.0))
+    save("traj_greedy_max256.npz", gen_trajectories(ref, "greedy_max256", 2024, 16, 768, "greedy",
+                                                    max_tile=256))
+    save("traj_noautoreset.npz", gen_trajectories(ref, "noautoreset", 5, 16, 96, "random", auto_reset=False))
+    validate(ref, args.validate_steps, report)
+    time_reference(ref, report)
+    with open(os.path.join(HERE, "VALIDATION.txt"), "w") as f:
+        f.write("\n".join(report) + "\n")
+    print("\n".join(report))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+// host_check.cpp -- TEST HARNESS ONLY: compiles the device header g2048_device.h with g++
+// (-DG2048_HOST_CHECK) so that the exact byte-parallel arithmetic the gfx950 kernels run can be
+// unit-tested against the oracle in a container that has no GPU.  It mirrors the bodies of
+// step_kernel / reset_kernel (g2048_kernels.hip) one board at a time.  Not part of the product.
+#define G2048_HOST_CHECK 1
+#include "../../gym-2048_amd/csrc/g2048_device.h"
+#include "../../oracle/g2048_oracle.h"
+
+#include <cstring>
+
+using namespace g2048;
+
+static Board load_board(const uint8_t *b)
+{
+    Board bd;
+    std::memcpy(bd.r, b, 16);
+    return bd;
+}
+static void store_board(uint8_t *b, const Board &bd) { std::memcpy(b, bd.r, 16); }
+
+extern "C" {
+
+void hostcheck_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    const Words w = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    std::memcpy(out, w.w, 16);
+}
+
+// one line through shift4 (byte lane `lane` of the four SWAR registers; other lanes get junk rows)
+uint32_t hostcheck_shift(const uint8_t row[4], uint8_t out[4], int lane, const uint8_t junk[12])
+{
+    uint32_t r[4] = {0, 0, 0, 0};
+    int j = 0;
+    for (int l = 0; l < 4; ++l)
+        for (int k = 0; k < 4; ++k)
+            r[k] |= (uint32_t)(l == lane ? row[k] : junk[j++ % 12]) << (8 * l);
+    // score of the junk lanes alone
+    uint32_t rj[4];
+    for (int k = 0; k < 4; ++k)
+        rj[k] = r[k] & ~(0xffu << (8 * lane));
+    uint32_t a = r[0], b = r[1], c = r[2], d = r[3];
+    const uint32_t total = shift4(a, b, c, d);
+    const uint32_t junk_score = shift4(rj[0], rj[1], rj[2], rj[3]);
+    out[0] = (a >> (8 * lane)) & 0xff;
+    out[1] = (b >> (8 * lane)) & 0xff;
+    out[2] = (c >> (8 * lane)) & 0xff;
+    out[3] = (d >> (8 * lane)) & 0xff;
+    return total - junk_score;
+}
+
+int hostcheck_move(const uint8_t in[16], uint32_t action, uint8_t out[16], uint32_t *score)
+{
+    Board bd = load_board(in);
+    const bool legal = move(bd, action, *score);
+    store_board(out, bd);
+    return legal;
+}
+
+uint32_t hostcheck_highest(const uint8_t in[16]) { return highest(load_board(in)); }
+uint32_t hostcheck_count_empty(const uint8_t in[16]) { return count_empty(load_board(in)); }
+int hostcheck_has_equal_neighbours(const uint8_t in[16]) { return has_equal_neighbours(load_board(in)); }
+
+void hostcheck_add_tile(uint8_t b[16], uint32_t w)
+{
+    Board bd = load_board(b);
+    add_tile(bd, w);
+    store_board(b, bd);
+}
+
+void hostcheck_reset_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t, uint64_t board_offset,
+                           uint32_t first_slot, int)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t b = (uint32_t)(board_offset + i);
+        const Words w = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), b, first_slot >> 2, (uint32_t)seed,
+                                      (uint32_t)(seed >> 32));
+        const uint32_t sl = first_slot & 3u;
+        const uint32_t w1 = select_word(w, sl);
+        uint32_t w2;
+        if (sl == 3u)
+            w2 = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), b, (first_slot >> 2) + 1u, (uint32_t)seed,
+                               (uint32_t)(seed >> 32)).w[0];
+        else
+            w2 = select_word(w, sl + 1u);
+        store_board(s->boards + 16 * i, fresh_board(w1, w2));
+        s->score[i] = 0;
+        s->ep_start[i] = (uint32_t)t;
+    }
+}
+
+void hostcheck_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t, uint64_t board_offset,
+                          float illegal_move_reward, int max_exp, int auto_reset, int)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        Board bd = load_board(s->boards + 16 * i);
+        int32_t score = s->score[i];
+        const Words w = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(board_offset + i), 0u,
+                                      (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t action = s->actions ? (s->actions[i] & 3u) : (w.w[3] >> 30);
+        const StepResult r = step_env(bd, score, action, w, illegal_move_reward, (uint32_t)max_exp, auto_reset != 0);
+        if (s->reward) s->reward[i] = r.reward;
+        if (s->terminated) s->terminated[i] = r.terminated;
+        if (s->illegal) s->illegal[i] = r.illegal;
+        if (s->highest) s->highest[i] = (uint8_t)highest(r.terminal);
+        if (r.terminated) {
+            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, r.terminal);
+            s->last_score[i] = r.terminal_score;
+            s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
+            s->ep_count[i] += 1;
+            if (auto_reset) s->ep_start[i] = (uint32_t)t;
+        }
+        store_board(s->boards + 16 * i, bd);
+        s->score[i] = score;
+    }
+}
+
+} // extern "C"

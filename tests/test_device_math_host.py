@@ -1,0 +1,130 @@
+"""CPU: the byte-parallel board arithmetic of gym-2048_amd/csrc/g2048_device.h -- the exact header
+the gfx950 kernels are compiled from -- built for the host by tests/host_check and compared with the
+golden vectors and the oracle.  Catches logic errors here, where there is no GPU; the GPU tests then
+prove the same on the device."""
+import ctypes as C
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import TRAJECTORIES, load_golden, replay_trajectory
+from oracle import OracleBatch, _Batch
+
+U8P = C.POINTER(C.c_uint8)
+
+
+class HostCheckBatch(OracleBatch):
+    """OracleBatch-shaped driver whose reset/step run the device header's code."""
+
+    def __init__(self, hc, n, seed=0, board_offset=0):
+        super().__init__(n, seed, board_offset)
+        self.hc = hc
+        for f in (hc.hostcheck_reset_batch, hc.hostcheck_step_batch):
+            f.restype = None
+        hc.hostcheck_reset_batch.argtypes = self.lib.g2048o_reset_batch.argtypes
+        hc.hostcheck_step_batch.argtypes = self.lib.g2048o_step_batch.argtypes
+
+    def reset(self, first_slot=0, new_transaction=None):
+        if new_transaction is None:
+            new_transaction = not self.fresh
+        if new_transaction:
+            self.t += 1
+        self.fresh = False
+        b = self._batch()
+        self.hc.hostcheck_reset_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset, first_slot, 1)
+
+    def step(self, actions=None, auto_reset=True):
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        self.t += 1
+        self.fresh = False
+        b = self._batch(actions)
+        self.hc.hostcheck_step_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset,
+                                     self.illegal_move_reward, self.max_exp, int(auto_reset), 1)
+
+
+def test_philox(host_check):
+    out = (C.c_uint32 * 4)()
+    host_check.hostcheck_philox((C.c_uint32 * 4)(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+                                (C.c_uint32 * 2)(0xa4093822, 0x299f31d0), out)
+    assert tuple(out) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+def test_shift4_exhaustive(host_check):
+    g = load_golden("shift_exhaustive")
+    rng = np.random.default_rng(1)
+    junk_all = rng.integers(0, 18, size=(18 ** 4, 12)).astype(np.uint8)
+    for i, exps in enumerate(itertools.product(range(18), repeat=4)):
+        out = (C.c_uint8 * 4)()
+        sc = host_check.hostcheck_shift((C.c_uint8 * 4)(*exps), out, i % 4, junk_all[i].ctypes.data_as(U8P))
+        assert list(out) == list(g["out"][i]) and sc == g["score"][i], exps
+
+
+def test_move_query_tables(host_check):
+    m = load_golden("move_table")
+    for i in range(len(m["boards"])):
+        b = np.ascontiguousarray(m["boards"][i])
+        p = b.ctypes.data_as(U8P)
+        assert host_check.hostcheck_highest(p) == m["highest"][i]
+        assert host_check.hostcheck_count_empty(p) == int((b == 0).sum())
+        for d in range(4):
+            out = np.zeros(16, np.uint8)
+            sc = C.c_uint32()
+            legal = host_check.hostcheck_move(p, d, out.ctypes.data_as(U8P), C.byref(sc))
+            assert legal == m["legal"][i, d]
+            assert np.array_equal(out, m["new"][i, d]) and sc.value == m["score"][i, d]
+    t = load_golden("isend_table")
+    full = [(b, e) for b, e in zip(t["boards"], t["isend"]) if (b != 0).all()]
+    for b, _ in full:
+        b = np.ascontiguousarray(b)
+        v = b.reshape(4, 4)
+        want = bool((v[:, :-1] == v[:, 1:]).any() or (v[:-1] == v[1:]).any())
+        assert bool(host_check.hostcheck_has_equal_neighbours(b.ctypes.data_as(U8P))) == want
+
+
+def test_add_tile_matches_oracle(host_check, oracle_lib):
+    rng = np.random.default_rng(3)
+    I64x16 = C.c_int64 * 16
+    for _ in range(4000):
+        fill = rng.integers(0, 16)
+        b = np.zeros(16, np.uint8)
+        b[rng.choice(16, size=fill, replace=False)] = rng.integers(1, 12, size=fill)
+        w = int(rng.integers(0, 2 ** 32))
+        M = I64x16(*[0 if e == 0 else 1 << int(e) for e in b])
+        oracle_lib.g2048o_add_tile(M, w)
+        want = [0 if v == 0 else int(v).bit_length() - 1 for v in M]
+        got = b.copy()
+        host_check.hostcheck_add_tile(got.ctypes.data_as(U8P), w)
+        assert list(got) == want
+
+
+@pytest.mark.parametrize("name", TRAJECTORIES)
+def test_golden_trajectories(host_check, name):
+    replay_trajectory(lambda n, seed, off: HostCheckBatch(host_check, n, seed, off), load_golden(name))
+
+
+@pytest.mark.parametrize("seed,offset,irw,max_exp,auto_reset", [
+    (11, 0, 0.0, 0, True), (12, (1 << 32) - 4096, -1.0, 0, True), (13, 77, -2.5, 5, True), (14, 0, 0.0, 0, False)])
+def test_random_rollouts_vs_oracle(host_check, seed, offset, irw, max_exp, auto_reset):
+    n, steps = 4096, 96
+    a, b = OracleBatch(n, seed, offset), HostCheckBatch(host_check, n, seed, offset)
+    for o in (a, b):
+        o.illegal_move_reward, o.max_exp = irw, max_exp
+        o.reset()
+    assert np.array_equal(a.boards, b.boards)
+    for s in range(steps):
+        for o in (a, b):
+            o.step(None, auto_reset=auto_reset)
+        for f in ("boards", "score", "reward", "terminated", "illegal", "highest", "last_score", "last_len",
+                  "ep_count", "ep_start", "terminal_boards"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (f, s)
+    assert a.ep_count.sum() > 100
+
+
+def test_reset_slots(host_check):
+    for first_slot in range(0, 7):
+        a, b = OracleBatch(64, 5), HostCheckBatch(host_check, 64, 5)
+        a.reset(first_slot=first_slot, new_transaction=False)
+        b.reset(first_slot=first_slot, new_transaction=False)
+        assert np.array_equal(a.boards, b.boards), first_slot

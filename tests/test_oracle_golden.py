@@ -1,0 +1,185 @@
+"""CPU: the oracle (C and Python halves) against the golden vectors captured from the imported
+reference (tests/golden/make_golden.py).  This is what pins the checker used by the GPU tests."""
+import ctypes as C
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import TRAJECTORIES, load_golden, replay_trajectory
+from oracle import OracleBatch
+from oracle import cpu_ref
+
+I64x4 = C.c_int64 * 4
+I64x16 = C.c_int64 * 16
+
+
+def vals(exps):
+    return [0 if e == 0 else 1 << int(e) for e in exps]
+
+
+def test_philox_known_answers(oracle_lib):
+    # Random123 / rocrand known-answer vectors for Philox4x32-10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        out = (C.c_uint32 * 4)()
+        oracle_lib.g2048o_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert tuple(out) == want
+        assert cpu_ref.philox4x32_10(ctr, key) == want
+        got = cpu_ref.philox4x32_10_np(*[np.array([c]) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_spawn_word_layout(oracle_lib):
+    for seed, t, board, slot in [(42, 0, 0, 0), (42, 1, 5, 2), ((1 << 63) + 12345, (1 << 40) + 7, 0xfffffff0, 6)]:
+        w = oracle_lib.g2048o_spawn_word(seed, t, board, slot)
+        assert w == cpu_ref.spawn_word(seed, t, board, slot)
+        ctr = (t & 0xffffffff, t >> 32, board, slot >> 2)
+        assert w == cpu_ref.philox4x32_10(ctr, (seed & 0xffffffff, seed >> 32))[slot & 3]
+        assert oracle_lib.g2048o_random_action(seed, t, board) == cpu_ref.spawn_word(seed, t, board, 3) >> 30
+    acts = cpu_ref.random_actions_np(42, 9, (1 << 20) - 3, 8)
+    assert list(acts) == [cpu_ref.random_action(42, 9, (1 << 20) - 3 + i) for i in range(8)]
+
+
+def test_spawn_value_threshold(oracle_lib):
+    # random() := (w & 0xffff) / 65536 < 0.9  <=>  (w & 0xffff) <= 58982
+    for low in (0, 58981, 58982, 58983, 65535):
+        want = 2 if low / 65536.0 < 0.9 else 4
+        assert oracle_lib.g2048o_spawn_value(0xabcd0000 | low) == want
+        assert (2 if low <= cpu_ref.TWO_THRESHOLD else 4) == want
+
+
+def test_shift_exhaustive(oracle_lib):
+    g = load_golden("shift_exhaustive")
+    for i, exps in enumerate(itertools.product(range(18), repeat=4)):
+        out = I64x4()
+        score = oracle_lib.g2048o_shift(I64x4(*vals(exps)), out)
+        assert list(cpu_ref.values_to_exp(list(out))) == list(g["out"][i]) and score == g["score"][i], exps
+        if i % 37 == 0:
+            new, ms = cpu_ref.RefEnv.shift(vals(exps))
+            assert list(cpu_ref.values_to_exp(new)) == list(g["out"][i]) and ms == g["score"][i]
+
+
+def test_reference_unit_test_values(oracle_lib):
+    """The values the reference's own test file pins (re-captured by calling the reference)."""
+    k = load_golden("reference_test_kats")
+    for row, out, score in zip(k["shift_rows"], k["shift_out"], k["shift_score"]):
+        got = I64x4()
+        assert oracle_lib.g2048o_shift(I64x4(*row), got) == score
+        assert list(got) == list(out)
+    # hard-coded spot values from test_game2048_env.py:20-30 as a guard on the fixture itself
+    assert list(k["shift_out"][5]) == [4, 4, 4, 0] and k["shift_score"][5] == 4      # [4,2,2,4]
+    assert list(k["shift_out"][10]) == [8, 8, 0, 0] and k["shift_score"][10] == 16   # [4,4,4,4]
+    assert list(k["move_score"]) == [12, 20, 12, 20]
+    for d in range(4):
+        M = I64x16(*k["move_board"].reshape(16))
+        sc = C.c_int64()
+        assert oracle_lib.g2048o_move(M, d, 0, C.byref(sc)) == 1
+        assert sc.value == k["move_score"][d]
+        assert list(M) == list(k["move_out"][d].reshape(16))
+        e = cpu_ref.RefEnv()
+        e.M = [int(v) for v in k["move_board"].reshape(16)]
+        assert e.move(d) == k["move_score"][d] and e.M == list(k["move_out"][d].reshape(16))
+    assert bool(k["repeat_illegal"])
+    M = I64x16(*k["move_out"][3].reshape(16))
+    sc = C.c_int64()
+    assert oracle_lib.g2048o_move(M, 3, 0, C.byref(sc)) == 0          # repeat left is illegal
+    assert oracle_lib.g2048o_move(M, 2, 0, C.byref(sc)) == 1 and sc.value == k["follow_score"] == 8
+    assert list(M) == list(k["follow_board"].reshape(16))
+    assert list(k["step_rewards"]) == [4.0, 8.0] and k["step_score_after"] == 12.0
+    assert list(k["illegal_step"]) == [-1.0, 1.0, 1.0]
+
+
+def test_move_isend_highest_tables(oracle_lib):
+    m = load_golden("move_table")
+    for i in range(len(m["boards"])):
+        base = vals(m["boards"][i])
+        assert oracle_lib.g2048o_isend(I64x16(*base), 0) == m["isend"][i]
+        assert oracle_lib.g2048o_highest(I64x16(*base)) == (1 << int(m["highest"][i]) if m["highest"][i] else 0)
+        for d in range(4):
+            M = I64x16(*base)
+            sc = C.c_int64()
+            legal = oracle_lib.g2048o_move(M, d, 0, C.byref(sc))
+            assert legal == m["legal"][i, d]
+            assert list(cpu_ref.values_to_exp(list(M))) == list(m["new"][i, d])
+            assert sc.value == m["score"][i, d]
+            T = I64x16(*base)
+            assert oracle_lib.g2048o_move(T, d, 1, C.byref(sc)) == legal and list(T) == base  # trial
+    t = load_golden("isend_table")
+    for b, mx, want in zip(t["boards"], t["max_exp"], t["isend"]):
+        assert oracle_lib.g2048o_isend(I64x16(*vals(b)), (1 << int(mx)) if mx else 0) == want
+        e = cpu_ref.RefEnv()
+        e.M, e.max_tile = vals(b), ((1 << int(mx)) if mx else None)
+        assert e.isend() == bool(want)
+
+
+def test_stack_table(oracle_lib):
+    s = load_golden("stack_table")
+    out = np.zeros((len(s["boards"]), 16, 4, 4), np.uint8)
+    oracle_lib.g2048o_onehot_batch(s["boards"].ctypes.data, len(s["boards"]), out.ctypes.data)
+    assert np.array_equal(out, s["onehot"])
+    assert np.array_equal(cpu_ref.onehot(cpu_ref.exp_to_values(s["boards"]).reshape(-1, 4, 4)), s["onehot"])
+    assert s["onehot"][1].sum() == 14  # 2^16 and 2^17 have no layer (game2048_env.py:28)
+
+
+def test_csv_fixture(oracle_lib):
+    """data/test_data.csv of the reference: 848 recorded transitions; reward == move score, the next
+    board is the moved board plus one spawned 2/4 in a previously empty cell."""
+    c = load_golden("test_data_csv")
+    assert len(c["boards"]) == 848
+    for i in range(848):
+        M = I64x16(*vals(c["boards"][i]))
+        sc = C.c_int64()
+        assert oracle_lib.g2048o_move(M, int(c["actions"][i]), 0, C.byref(sc)) == 1
+        assert sc.value == int(c["rewards"][i])
+        moved = cpu_ref.values_to_exp(list(M))
+        assert list(moved) == list(c["moved"][i])
+        diff = np.flatnonzero(moved != c["next_boards"][i])
+        assert len(diff) == 1 and moved[diff[0]] == 0 and c["next_boards"][i][diff[0]] in (1, 2)
+    assert c["done"][-1] == 1 and bool(c["last_isend_max2048"])
+    assert oracle_lib.g2048o_isend(I64x16(*vals(c["next_boards"][-1])), 2048) == 1
+    assert oracle_lib.g2048o_isend(I64x16(*vals(c["next_boards"][-1])), 0) == 0
+
+
+@pytest.mark.parametrize("name", TRAJECTORIES)
+def test_trajectories_c_oracle(name):
+    replay_trajectory(lambda n, seed, off: OracleBatch(n, seed, off), load_golden(name))
+
+
+@pytest.mark.parametrize("name", ["traj_random_seed42", "traj_greedy_max256", "traj_noautoreset"])
+def test_trajectories_python_oracle(name):
+    d = load_golden(name)
+    seed, offset, n, steps, max_exp, auto_reset = (int(x) for x in d["meta"])
+    for b in range(0, n, 4):
+        e = cpu_ref.RefEnv(seed, offset + b)
+        e.illegal_move_reward = float(d["illegal_move_reward"][0])
+        e.max_tile = (1 << max_exp) if max_exp else None
+        e.reset()
+        assert list(cpu_ref.values_to_exp(e.M)) == list(d["initial_boards"][b])
+        for s in range(min(steps, 128)):
+            rw, term, ill, hi = e.step(int(d["actions"][b, s]))
+            assert (rw, term, ill) == (d["reward"][b, s], bool(d["terminated"][b, s]), bool(d["illegal"][b, s]))
+            assert hi == 1 << int(d["highest"][b, s])
+            if term and auto_reset:
+                e.reset()
+            assert list(cpu_ref.values_to_exp(e.M)) == list(d["boards"][b, s])
+            assert e.score == d["score"][b, s]
+
+
+def test_oracle_threads_and_reset_slots():
+    a, b = OracleBatch(300, 9, threads=1), OracleBatch(300, 9, threads=4)
+    for o in (a, b):
+        o.reset()
+        for _ in range(40):
+            o.step(None)
+    assert np.array_equal(a.boards, b.boards) and np.array_equal(a.score, b.score)
+    # a reset continuing at slot 3 crosses into the next Philox block of the transaction
+    c = OracleBatch(4, 1)
+    c.reset(first_slot=3, new_transaction=False)
+    e = cpu_ref.RefEnv(1, 2)
+    e.slot = 3
+    e.reset()
+    assert list(cpu_ref.values_to_exp(e.M)) == list(c.boards[2])
