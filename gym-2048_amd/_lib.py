@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class G2048Error(RuntimeError):
@@ -37,8 +37,8 @@ class Stats(C.Structure):
     """g2048_stats (include/g2048.h)."""
     _fields_ = [
         ("episodes", C.c_uint64),
+        ("illegal_ends", C.c_uint64),
         ("score_sum", C.c_int64),
-        ("length_sum", C.c_int64),
         ("max_score", C.c_int32),
         ("max_exp", C.c_uint32),
     ]
@@ -73,7 +73,7 @@ SIGNATURES = {
     "g2048_set_boards": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_set_scores": (C.c_int, [_E, C.c_void_p, _S]),
-    "g2048_get_episode_records": (C.c_int, [_E, C.c_void_p, C.c_void_p, C.c_void_p, _S]),
+    "g2048_get_last_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_boards_ptr": (C.c_void_p, [_E]),
     "g2048_scores_ptr": (C.c_void_p, [_E]),
     "g2048_last_score_ptr": (C.c_void_p, [_E]),

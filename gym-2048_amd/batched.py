@@ -266,21 +266,19 @@ class Batched2048:
         assert s.size == self.n_envs
         check(self._lib.g2048_set_scores(self._h, s.ctypes.data, self._stream()))
 
-    def episode_records(self):
-        """Host copies ``(last_score int32[n], last_len int32[n], ep_count uint32[n])``."""
-        ls, ll = np.empty(self.n_envs, np.int32), np.empty(self.n_envs, np.int32)
-        ec = np.empty(self.n_envs, np.uint32)
-        check(self._lib.g2048_get_episode_records(self._h, ls.ctypes.data, ll.ctypes.data, ec.ctypes.data,
-                                                  self._stream()))
-        return ls, ll, ec
+    def get_last_scores(self) -> np.ndarray:
+        """Host copy ``int32[n]``: final score of each board's most recently finished episode."""
+        buf = np.empty(self.n_envs, np.int32)
+        check(self._lib.g2048_get_last_scores(self._h, buf.ctypes.data, self._stream()))
+        return buf
 
     def episode_stats(self) -> dict:
+        """Aggregate over all episodes finished since create/seed (reduced on the device)."""
         st = Stats()
         check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
-        return dict(episodes=st.episodes, score_sum=st.score_sum, length_sum=st.length_sum,
+        return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, score_sum=st.score_sum,
                     max_score=st.max_score, max_exp=st.max_exp,
-                    mean_score=(st.score_sum / st.episodes) if st.episodes else 0.0,
-                    mean_length=(st.length_sum / st.episodes) if st.episodes else 0.0)
+                    mean_score=(st.score_sum / st.episodes) if st.episodes else 0.0)
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:

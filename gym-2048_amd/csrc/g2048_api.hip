@@ -111,7 +111,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 1; }
+int g2048_abi_version(void) { return 2; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -141,13 +141,9 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     const size_t n = n_boards;
     const size_t off_boards = 0;
     const size_t off_score = off_boards + align_up(n * 16);
-    const size_t off_ep_start = off_score + align_up(n * 4);
-    const size_t off_last_score = off_ep_start + align_up(n * 4);
-    const size_t off_last_len = off_last_score + align_up(n * 4);
-    const size_t off_ep_count = off_last_len + align_up(n * 4);
-    const size_t off_score_sum = off_ep_count + align_up(n * 4);
-    const size_t off_len_sum = off_score_sum + align_up(n * 8);
-    const size_t off_stats = off_len_sum + align_up(n * 8);
+    const size_t off_last_score = off_score + align_up(n * 4);
+    const size_t off_wave_stats = off_last_score + align_up(n * 4);
+    const size_t off_stats = off_wave_stats + align_up(((n + 63) / 64) * sizeof(g2048::WaveStats));
     e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
     err = hipMalloc(&e->slab, e->slab_bytes);
     if (err != hipSuccess) {
@@ -163,12 +159,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     char *base = static_cast<char *>(e->slab);
     e->st.boards = reinterpret_cast<uint4 *>(base + off_boards);
     e->st.score = reinterpret_cast<int32_t *>(base + off_score);
-    e->st.ep_start = reinterpret_cast<uint32_t *>(base + off_ep_start);
     e->st.last_score = reinterpret_cast<int32_t *>(base + off_last_score);
-    e->st.last_len = reinterpret_cast<int32_t *>(base + off_last_len);
-    e->st.ep_count = reinterpret_cast<uint32_t *>(base + off_ep_count);
-    e->st.score_sum = reinterpret_cast<int64_t *>(base + off_score_sum);
-    e->st.len_sum = reinterpret_cast<int64_t *>(base + off_len_sum);
+    e->st.wave_stats = reinterpret_cast<g2048::WaveStats *>(base + off_wave_stats);
     e->stats_dev = reinterpret_cast<g2048::StatsOut *>(base + off_stats);
     *out = e;
     return G2048_OK;
@@ -196,6 +188,10 @@ int g2048_seed(g2048_engine *e, uint64_t seed)
     e->seed = seed;
     e->t = 0;
     e->fresh = 1;
+    // episode statistics restart with the stream
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(hipMemset(e->st.last_score, 0, e->n * 4));
+    G2048_HIP(hipMemset(e->st.wave_stats, 0, ((e->n + 63) / 64) * sizeof(g2048::WaveStats)));
     return G2048_OK;
 }
 
@@ -404,21 +400,9 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
     return copy_in(e, e ? e->st.score : nullptr, buf, e ? e->n * 4 : 0, stream);
 }
 
-int g2048_get_episode_records(const g2048_engine *e, int32_t *last_score, int32_t *last_len, uint32_t *ep_count,
-                              void *stream)
+int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
-    if (last_score)
-        if (int rc = copy_out(e, last_score, e->st.last_score, e->n * 4, stream))
-            return rc;
-    if (last_len)
-        if (int rc = copy_out(e, last_len, e->st.last_len, e->n * 4, stream))
-            return rc;
-    if (ep_count)
-        if (int rc = copy_out(e, ep_count, e->st.ep_count, e->n * 4, stream))
-            return rc;
-    return G2048_OK;
+    return copy_out(e, buf, e ? e->st.last_score : nullptr, e ? e->n * 4 : 0, stream);
 }
 
 void *g2048_boards_ptr(const g2048_engine *e) { return e ? e->st.boards : nullptr; }
@@ -436,8 +420,8 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     G2048_HIP(hipMemcpyAsync(&h, e->stats_dev, sizeof h, hipMemcpyDeviceToHost, s));
     G2048_HIP(hipStreamSynchronize(s));
     out->episodes = h.episodes;
-    out->score_sum = h.score_sum;
-    out->length_sum = h.length_sum;
+    out->illegal_ends = h.illegal_ends;
+    out->score_sum = static_cast<int64_t>(h.score_sum);
     out->max_score = h.max_score;
     out->max_exp = h.max_exp;
     return G2048_OK;

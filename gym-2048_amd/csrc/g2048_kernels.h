@@ -7,16 +7,23 @@
 
 namespace g2048 {
 
+// Per-wavefront episode accumulators: the only episode bookkeeping the hot kernel touches besides
+// last_score.  One slot per 64 boards, updated by lane 0 with fire-and-forget atomics, so a step
+// adds no per-board read-modify-write traffic.
+struct WaveStats {
+    unsigned int episodes;        // finished episodes
+    unsigned int illegal_ends;    // ... of which ended on an illegal move
+    unsigned long long score_sum; // sum of final merge scores
+    int max_score;
+    int pad;
+};
+
 // Engine-owned device state (one slab).
 struct DeviceState {
-    uint4 *boards;        // [n]   16 x int8 exponents per board
-    int32_t *score;       // [n]   episodic merge score (game2048_env.py:86)
-    uint32_t *ep_start;   // [n]   low 32 bits of the transaction that started the episode
-    int32_t *last_score;  // [n]   record of the last finished episode
-    int32_t *last_len;    // [n]
-    uint32_t *ep_count;   // [n]   finished episodes
-    int64_t *score_sum;   // [n]   sum of final scores over finished episodes
-    int64_t *len_sum;     // [n]
+    uint4 *boards;         // [n]   16 x int8 exponents per board
+    int32_t *score;        // [n]   episodic merge score (game2048_env.py:86)
+    int32_t *last_score;   // [n]   final score of the board's last finished episode (write-only here)
+    WaveStats *wave_stats; // [ceil(n/64)]
 };
 
 struct StepArgs {
@@ -39,8 +46,8 @@ struct StepArgs {
 
 struct StatsOut {
     unsigned long long episodes;
-    long long score_sum;
-    long long length_sum;
+    unsigned long long illegal_ends;
+    unsigned long long score_sum;
     int max_score;
     unsigned int max_exp;
 };

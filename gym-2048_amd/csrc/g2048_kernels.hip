@@ -14,6 +14,7 @@
 
 #include "g2048_device.h"
 
+
 namespace g2048 {
 
 constexpr int kBlock = 256;
@@ -31,24 +32,54 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
         return static_cast<uint32_t>(static_cast<const long long *>(actions)[i]) & 3u;
 }
 
-// Episode bookkeeping for a board whose step terminated: the record of the finished episode
-// (touched only by the ~7 % of lanes that end an episode under a random policy).
-__device__ __forceinline__ void record_episode(const StepArgs &p, uint32_t i, const StepResult &r, uint32_t t_lo)
+// Episode bookkeeping.  Boards that ended an episode write their final score (and, if asked, their
+// terminal board); the wave's totals go to its WaveStats slot.  The whole block is skipped by a
+// wave-uniform branch when no lane terminated.
+struct WaveAcc {
+    unsigned int episodes = 0, illegal_ends = 0;
+    unsigned long long score_sum = 0;
+    int max_score = 0;
+};
+
+__device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, const StepResult &r, WaveAcc &acc)
 {
-    if (p.terminal_boards)
-        p.terminal_boards[i] = make_uint4(r.terminal.r[0], r.terminal.r[1], r.terminal.r[2], r.terminal.r[3]);
-    const int32_t len = static_cast<int32_t>(t_lo - p.st.ep_start[i]);
-    p.st.last_score[i] = r.terminal_score;
-    p.st.last_len[i] = len;
-    p.st.ep_count[i] += 1u;
-    p.st.score_sum[i] += r.terminal_score;
-    p.st.len_sum[i] += len;
-    if (p.auto_reset)
-        p.st.ep_start[i] = t_lo;
+    const unsigned long long done = __ballot(r.terminated);
+    if (done == 0)
+        return;
+    if (r.terminated) {
+        p.st.last_score[i] = r.terminal_score;
+        if (p.terminal_boards)
+            p.terminal_boards[i] = make_uint4(r.terminal.r[0], r.terminal.r[1], r.terminal.r[2], r.terminal.r[3]);
+    }
+    acc.episodes += static_cast<unsigned int>(__popcll(done));
+    acc.illegal_ends += static_cast<unsigned int>(__popcll(__ballot(r.terminated && r.illegal)));
+    for (unsigned long long m = done; m != 0; m &= m - 1) { // scalar walk over the few finished lanes
+        const int v = __builtin_amdgcn_readlane(r.terminal_score, __ffsll(static_cast<long long>(m)) - 1);
+        acc.score_sum += static_cast<unsigned long long>(static_cast<long long>(v));
+        acc.max_score = max(acc.max_score, v);
+    }
+}
+
+__device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, const WaveAcc &acc)
+{
+    if (acc.episodes == 0 || (threadIdx.x & 63u) != 0)
+        return;
+    WaveStats *ws = p.st.wave_stats + (i >> 6);
+    atomicAdd(&ws->episodes, acc.episodes);
+    if (acc.illegal_ends)
+        atomicAdd(&ws->illegal_ends, acc.illegal_ends);
+    atomicAdd(&ws->score_sum, acc.score_sum);
+    atomicMax(&ws->max_score, acc.max_score);
 }
 
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
+//
+// One board per lane, one pass: load (board 16 B, score 4 B, action) -> ~330 VALU instructions ->
+// store.  The Philox block does not depend on the loaded data, so its ~55 instructions run while
+// the loads are in flight.  Measured alternatives that were NOT faster on MI355X at 2^20 boards
+// (tools/ubench/step_variants.hip): grid-stride loops with the next board prefetched, per-block
+// s_setprio staggering, 32-bit offset addressing.
 template <int ACT>
 __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
 {
@@ -64,6 +95,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
 
     const StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
 
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    p.st.score[i] = score;
     if (p.reward)
         p.reward[i] = r.reward;
     if (p.terminated)
@@ -72,11 +105,9 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
         p.illegal[i] = r.illegal ? 1 : 0;
     if (p.highest)
         p.highest[i] = static_cast<uint8_t>(highest(r.terminal)); // :97
-    if (r.terminated)
-        record_episode(p, i, r, p.t_lo);
-
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-    p.st.score[i] = score;
+    WaveAcc acc;
+    record_episodes(p, i, r, acc);
+    flush_wave_stats(p, i, acc);
 }
 
 // ------------------------------------------------------------------------- fused rollout
@@ -90,15 +121,16 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     Board bd{{v.x, v.y, v.z, v.w}};
     int32_t score = p.st.score[i];
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
+    WaveAcc acc;
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
-        const uint32_t t_lo = static_cast<uint32_t>(t), t_hi = static_cast<uint32_t>(t >> 32);
-        const Words w = philox4x32_10(t_lo, t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+        const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
+                                      p.seed_lo, p.seed_hi);
         const StepResult r = step_env(bd, score, w.w[3] >> 30, w, p.illegal_reward, p.max_exp, true);
-        if (r.terminated)
-            record_episode(p, i, r, t_lo);
+        record_episodes(p, i, r, acc);
     }
     p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
     p.st.score[i] = score;
+    flush_wave_stats(p, i, acc);
 }
 
 // ---------------------------------------------------------------------------------- reset
@@ -122,7 +154,6 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const StepArgs p, uint32_
     const Board bd = fresh_board(w1, w2);
     p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
     p.st.score[i] = 0; // :105
-    p.st.ep_start[i] = p.t_lo;
 }
 
 // ------------------------------------------------------------------------- game primitives
@@ -235,46 +266,47 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
 }
 
 // ----------------------------------------------------------------------------------- stats
-__device__ __forceinline__ long long wave_sum(long long x)
+// Reduce the per-wave accumulators (and the highest tile on any board) to one StatsOut.
+// Block-level tree in LDS first, then ONE set of atomics per block (a single hot word serialises at
+// ~88 atomics/us on this chip, so per-wave atomics to one address would take hundreds of us).
+__global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
+                                                       StatsOut *out)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        x += __shfl_down(x, off, 64);
-    return x;
-}
-__device__ __forceinline__ int wave_max(int x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        x = max(x, __shfl_down(x, off, 64));
-    return x;
-}
-
-__global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, StatsOut *out)
-{
-    long long episodes = 0, score_sum = 0, len_sum = 0;
+    __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock];
+    __shared__ int s_max[kBlock], s_exp[kBlock];
+    unsigned long long episodes = 0, illegal = 0, score_sum = 0;
     int max_score = 0, max_exp = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const uint32_t c = st.ep_count[i];
-        episodes += c;
-        score_sum += st.score_sum[i];
-        len_sum += st.len_sum[i];
-        if (c)
-            max_score = max(max_score, st.last_score[i]);
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t wv = blockIdx.x * kBlock + threadIdx.x; wv < n_waves; wv += stride) {
+        const WaveStats ws = st.wave_stats[wv];
+        episodes += ws.episodes;
+        illegal += ws.illegal_ends;
+        score_sum += ws.score_sum;
+        max_score = max(max_score, ws.max_score);
+    }
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint4 v = st.boards[i];
         max_exp = max(max_exp, static_cast<int>(highest(Board{{v.x, v.y, v.z, v.w}})));
     }
-    episodes = wave_sum(episodes);
-    score_sum = wave_sum(score_sum);
-    len_sum = wave_sum(len_sum);
-    max_score = wave_max(max_score);
-    max_exp = wave_max(max_exp);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&out->episodes, static_cast<unsigned long long>(episodes));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&out->score_sum), static_cast<unsigned long long>(score_sum));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&out->length_sum), static_cast<unsigned long long>(len_sum));
-        atomicMax(&out->max_score, max_score);
-        atomicMax(&out->max_exp, static_cast<unsigned int>(max_exp));
+    const uint32_t tid = threadIdx.x;
+    s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_max[tid] = max_score; s_exp[tid] = max_exp;
+    __syncthreads();
+    for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+            s_ep[tid] += s_ep[tid + off];
+            s_ill[tid] += s_ill[tid + off];
+            s_sum[tid] += s_sum[tid + off];
+            s_max[tid] = max(s_max[tid], s_max[tid + off]);
+            s_exp[tid] = max(s_exp[tid], s_exp[tid + off]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(&out->episodes, s_ep[0]);
+        atomicAdd(&out->illegal_ends, s_ill[0]);
+        atomicAdd(&out->score_sum, s_sum[0]);
+        atomicMax(&out->max_score, s_max[0]);
+        atomicMax(&out->max_exp, static_cast<unsigned int>(s_exp[0]));
     }
 }
 
@@ -392,9 +424,9 @@ hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hi
     if (err != hipSuccess || n == 0)
         return err;
     uint32_t blocks = grid_for(n).x;
-    if (blocks > 2048u)
-        blocks = 2048u;
-    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, dev_out);
+    if (blocks > 512u)
+        blocks = 512u;
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, dev_out);
     return hipGetLastError();
 }
 

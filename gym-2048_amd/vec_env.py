@@ -43,6 +43,9 @@ class Vec2048:
         self._actions = None
         self._t0 = time.time()
         self._seed = seed
+        # Monitor-style per-env episode accounting (SB3's Monitor keeps these on the host as well)
+        self._ep_return = np.zeros(self.num_envs, np.float64)
+        self._ep_length = np.zeros(self.num_envs, np.int64)
 
     # ------------------------------------------------------------------ VecEnv API
     def seed(self, seed=None):
@@ -53,6 +56,8 @@ class Vec2048:
 
     def reset(self):
         self.engine.reset()
+        self._ep_return[:] = 0
+        self._ep_length[:] = 0
         return self._obs()
 
     def step_async(self, actions):
@@ -63,22 +68,23 @@ class Vec2048:
         dones = np.asarray(res["terminated"], dtype=bool)
         rewards = np.asarray(res["reward"], dtype=np.float32)
         obs = self._obs()
+        self._ep_return += rewards
+        self._ep_length += 1
         infos = [_EMPTY_INFO] * self.num_envs
         idx = np.flatnonzero(dones)
         if idx.size:
-            last_score, last_len, _ = self.engine.episode_records()
             terminal = _onehot_host(res["terminal_boards"][idx], self.obs_dtype)
             now = round(time.time() - self._t0, 6)
             for j, i in enumerate(idx):
-                illegal = bool(res["illegal"][i])
-                ret = float(last_score[i]) + (self._illegal_move_reward if illegal else 0.0)
                 infos[i] = {
-                    "illegal_move": illegal,
+                    "illegal_move": bool(res["illegal"][i]),
                     "highest": int(1 << int(res["highest"][i])) if res["highest"][i] else 0,
-                    "episode": {"r": ret, "l": int(last_len[i]), "t": now},
+                    "episode": {"r": float(self._ep_return[i]), "l": int(self._ep_length[i]), "t": now},
                     "terminal_observation": terminal[j],
                     "TimeLimit.truncated": False,
                 }
+            self._ep_return[idx] = 0
+            self._ep_length[idx] = 0
         return obs, rewards, dones, infos
 
     def step(self, actions):

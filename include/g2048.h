@@ -72,8 +72,8 @@ typedef struct {
 /* Aggregate episode statistics (whole life of the engine since create/seed). */
 typedef struct {
     uint64_t episodes;       /* finished episodes */
+    uint64_t illegal_ends;   /* ... of which ended on an illegal move (game2048_env.py:91-95) */
     int64_t score_sum;       /* sum of their final merge scores (game2048_env.py:86) */
-    int64_t length_sum;      /* sum of their lengths in steps */
     int32_t max_score;       /* best final score */
     uint32_t max_exp;        /* highest exponent currently on any board */
 } g2048_stats;
@@ -150,10 +150,9 @@ int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream);
 int g2048_get_scores(const g2048_engine *e, int32_t *buf, void *stream);
 int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream);
 
-/* Per-board record of the most recently finished episode (written when a step terminates):
- * last_score int32[n], last_len int32[n] (steps), ep_count uint32[n].  NULL = skip. */
-int g2048_get_episode_records(const g2048_engine *e, int32_t *last_score, int32_t *last_len, uint32_t *ep_count,
-                              void *stream);
+/* Final merge score of each board's most recently finished episode (written when a step
+ * terminates; 0 before the first one): int32[n], host or device. */
+int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream);
 
 /* Raw device pointers of the engine-owned state for zero-copy views (boards: uint8[n][16],
  * scores: int32[n], last_score: int32[n]).  Valid until g2048_destroy. */

@@ -1,0 +1,317 @@
+"""GPU: the HIP path (through the C ABI, via gym2048_amd.Batched2048) against the oracle and the
+golden vectors captured from the reference -- bit-exact boards / rewards / flags / scores."""
+import numpy as np
+import pytest
+
+from conftest import TRAJECTORIES, load_golden, replay_trajectory
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import __graft_entry__ as ge
+    ge.build()
+    return torch
+
+
+class GpuBatch:
+    """OracleBatch-shaped facade over Batched2048 so the same replay helper drives both."""
+
+    def __init__(self, torch, n, seed, offset):
+        from gym2048_amd.batched import Batched2048
+        self.torch = torch
+        self.eng = Batched2048(n, device=0, seed=seed, board_offset=offset)
+        self.n = n
+        self.illegal_move_reward = 0.0
+        self.max_exp = 0
+
+    def _sync_cfg(self):
+        self.eng.set_illegal_move_reward(self.illegal_move_reward)
+        self.eng.set_max_tile((1 << self.max_exp) if self.max_exp else None)
+
+    def _pull(self):
+        e = self.eng
+        self.boards = e.get_boards().reshape(self.n, 16)
+        self.score = e.get_scores()
+        self.reward = e.reward.cpu().numpy()
+        self.terminated = e.terminated.cpu().numpy()
+        self.illegal = e.illegal.cpu().numpy()
+        self.highest = e.highest.cpu().numpy()
+        self.terminal_boards = e.terminal_boards.cpu().numpy()
+        self.last_score = e.get_last_scores()
+
+    def reset(self, **kw):
+        self._sync_cfg()
+        self.eng.reset(**kw)
+        self._pull()
+
+    def step(self, actions=None, auto_reset=True):
+        if actions is not None:
+            actions = self.torch.as_tensor(np.ascontiguousarray(actions, dtype=np.uint8))
+        self.eng.step(actions, auto_reset=auto_reset)
+        self._pull()
+
+
+@pytest.mark.parametrize("name", TRAJECTORIES)
+def test_golden_trajectories(torch_cuda, name):
+    replay_trajectory(lambda n, seed, off: GpuBatch(torch_cuda, n, seed, off), load_golden(name))
+
+
+def test_move_table(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    m = load_golden("move_table")
+    n = len(m["boards"])
+    eng = Batched2048(n)
+    for d in range(4):
+        for trial in (True, False):
+            eng.set_boards(m["boards"])
+            score, legal = eng.move(torch.full((n,), d, dtype=torch.int64), trial=trial)
+            assert np.array_equal(score.cpu().numpy(), np.where(m["legal"][:, d], m["score"][:, d], 0))
+            assert np.array_equal(legal.cpu().numpy(), m["legal"][:, d])
+            want = m["boards"] if trial else m["new"][:, d]
+            assert np.array_equal(eng.get_boards().reshape(n, 16), want)
+    eng.set_boards(m["boards"])
+    end, hi = eng.query()
+    assert np.array_equal(end.cpu().numpy(), m["isend"]) and np.array_equal(hi.cpu().numpy(), m["highest"])
+
+
+def test_shift_exhaustive(torch_cuda):
+    """All 104 976 rows of shift() (exponents 0..17), four rows per board, as left moves."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    g = load_golden("shift_exhaustive")
+    rows = np.array(np.meshgrid(*[np.arange(18)] * 4, indexing="ij")).reshape(4, -1).T.astype(np.uint8)
+    n = len(rows) // 4
+    boards = rows.reshape(n, 16)
+    eng = Batched2048(n)
+    eng.set_boards(boards)
+    score, _ = eng.move(torch.full((n,), 3, dtype=torch.uint8))
+    assert np.array_equal(eng.get_boards().reshape(-1, 4), g["out"])
+    assert np.array_equal(score.cpu().numpy(), g["score"].reshape(n, 4).sum(axis=1))
+    # the same rows as columns (up) and reversed (right / down)
+    eng.set_boards(np.ascontiguousarray(boards.reshape(n, 4, 4).transpose(0, 2, 1)))
+    eng.move(torch.full((n,), 0, dtype=torch.int32))
+    assert np.array_equal(eng.get_boards().transpose(0, 2, 1).reshape(-1, 4), g["out"])
+    eng.set_boards(np.ascontiguousarray(boards.reshape(n, 4, 4)[:, :, ::-1]))
+    eng.move(torch.full((n,), 1, dtype=torch.int64))
+    assert np.array_equal(eng.get_boards()[:, :, ::-1].reshape(-1, 4), g["out"])
+    eng.set_boards(np.ascontiguousarray(boards.reshape(n, 4, 4).transpose(0, 2, 1)[:, ::-1, :]))
+    eng.move(torch.full((n,), 2, dtype=torch.int64))
+    assert np.array_equal(eng.get_boards()[:, ::-1, :].transpose(0, 2, 1).reshape(-1, 4), g["out"])
+
+
+def test_isend_and_csv_fixtures(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    t = load_golden("isend_table")
+    for mx in np.unique(t["max_exp"]):
+        sel = t["max_exp"] == mx
+        eng = Batched2048(int(sel.sum()), max_tile=(1 << int(mx)) if mx else None)
+        eng.set_boards(t["boards"][sel])
+        assert np.array_equal(eng.isend_numpy(), t["isend"][sel].astype(bool))
+    c = load_golden("test_data_csv")
+    eng = Batched2048(848)
+    eng.set_boards(c["boards"])
+    score, legal = eng.move(torch.as_tensor(c["actions"]))
+    assert legal.all() and np.array_equal(score.cpu().numpy(), c["rewards"].astype(np.int32))
+    assert np.array_equal(eng.get_boards().reshape(848, 16), c["moved"])
+    eng.set_boards(c["next_boards"])
+    eng.set_max_tile(2048)
+    assert eng.isend_numpy()[-1] and not eng.isend_numpy()[0]
+
+
+def test_onehot(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    s = load_golden("stack_table")
+    eng = Batched2048(len(s["boards"]))
+    eng.set_boards(s["boards"])
+    for dt in (torch.uint8, torch.float16, torch.float32):
+        got = eng.observe_onehot(dt).cpu().numpy()
+        assert np.array_equal(got, s["onehot"].astype(got.dtype))
+    assert np.array_equal(eng.tile_values().cpu().numpy().reshape(-1, 16),
+                          np.where(s["boards"] > 0, 1 << s["boards"].astype(np.int64), 0))
+
+
+@pytest.mark.parametrize("n,seed,offset,irw,max_tile,auto_reset", [
+    (65536, 42, 0, 0.0, None, True),           # BASELINE config 2 size
+    (5000, 7, (1 << 32) - 5000, -1.0, None, True),   # ragged size, top of the index space
+    (4097, 3, 12345, -0.5, 64, True),
+    (1024, 9, 0, 0.0, None, False),
+    (1, 5, 0, 0.0, None, True),                # a single board
+])
+def test_random_rollout_vs_oracle(torch_cuda, n, seed, offset, irw, max_tile, auto_reset):
+    from oracle import OracleBatch
+    torch = torch_cuda
+    g = GpuBatch(torch, n, seed, offset)
+    o = OracleBatch(n, seed, offset, threads=0)
+    for b in (g, o):
+        b.illegal_move_reward = irw
+        b.max_exp = int(np.log2(max_tile)) if max_tile else 0
+        b.reset()
+    assert np.array_equal(g.boards, o.boards)
+    score_sum = illegal_ends = max_score = 0
+    for s in range(64):
+        g.step(None, auto_reset=auto_reset)
+        o.step(None, auto_reset=auto_reset)
+        for f in ("boards", "score", "reward", "terminated", "illegal", "highest", "last_score"):
+            assert np.array_equal(getattr(g, f), getattr(o, f)), (f, s)
+        done = o.terminated.astype(bool)
+        assert np.array_equal(g.terminal_boards[done], o.terminal_boards[done])
+        score_sum += int(o.last_score[done].sum())
+        illegal_ends += int((o.illegal.astype(bool) & done).sum())
+        max_score = max([max_score] + o.last_score[done].tolist())
+    st = g.eng.episode_stats()
+    assert st["episodes"] == int(o.ep_count.sum()) and st["score_sum"] == score_sum
+    assert st["illegal_ends"] == illegal_ends and st["max_score"] == max_score
+    assert st["max_exp"] == int(o.boards.max())
+
+
+def test_action_dtypes_and_generated_actions(torch_cuda):
+    """u8 / i32 / i64 action buffers and the synthetic policy give identical trajectories; the
+    device-generated action tensor equals the CPU regeneration."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle.cpu_ref import random_actions_np
+    n, k, seed, off = 3000, 40, 21, 1 << 20
+    engs = [Batched2048(n, seed=seed, board_offset=off) for _ in range(4)]
+    for e in engs:
+        e.reset()
+    acts = engs[0].random_actions(k)
+    assert acts.shape == (k, n)
+    a_np = acts.cpu().numpy()
+    for j in range(0, k, 13):
+        assert np.array_equal(a_np[j], random_actions_np(seed, 1 + j, off, n))
+    for j in range(k):
+        engs[0].step(None)
+        engs[1].step(acts[j])
+        engs[2].step(acts[j].to(torch.int32))
+        engs[3].step(acts[j].to(torch.int64) + 4 * (j % 3))   # only the low two bits count
+        ref = engs[0].get_boards()
+        for e in engs[1:]:
+            assert np.array_equal(e.get_boards(), ref)
+            assert torch.equal(e.reward, engs[0].reward) and torch.equal(e.terminated, engs[0].terminated)
+
+
+def test_rollout_paths_agree(torch_cuda):
+    """k per-step launches (g2048_rollout with [k,n] buffers), the fused one-launch rollout and k
+    separate step() calls end in the same state; rollout buffers hold the per-step outputs."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    n, k, seed = 20000, 50, 99
+    a, b, c = (Batched2048(n, seed=seed) for _ in range(3))
+    for e in (a, b, c):
+        e.reset()
+    acts = a.random_actions(k)
+    rew = torch.zeros((k, n), dtype=torch.float32, device=a.device)
+    term = torch.zeros((k, n), dtype=torch.uint8, device=a.device)
+    a.rollout(acts, reward=rew, terminated=term)
+    b.rollout_random(k)
+    rewards, terms = [], []
+    for j in range(k):
+        c.step(None)
+        rewards.append(c.reward.clone())
+        terms.append(c.terminated.clone())
+    for e in (a, b):
+        assert np.array_equal(e.get_boards(), c.get_boards())
+        assert np.array_equal(e.get_scores(), c.get_scores())
+        assert np.array_equal(e.get_last_scores(), c.get_last_scores())
+        assert e.clock == c.clock == k
+        assert e.episode_stats() == c.episode_stats()
+    assert torch.equal(rew, torch.stack(rewards)) and torch.equal(term, torch.stack(terms))
+
+
+def test_full_size_invariants(torch_cuda):
+    """BASELINE's 2^20-board configuration: size-independent properties instead of a full oracle run.
+    (1) sharding invariance: board i of a 2^20 batch == board i of the 2-shard run;
+    (2) a 4096-board window of the big batch equals the oracle;
+    (3) conservation: sum of tile values changes by exactly the spawned tiles on legal, non-reset steps."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, k = 1 << 20, 42, 24
+    big = Batched2048(n, seed=seed)
+    lo = Batched2048(n // 2, seed=seed, board_offset=0)
+    hi = Batched2048(n // 2, seed=seed, board_offset=n // 2)
+    win_off = n - 4096
+    o = OracleBatch(4096, seed, win_off, threads=0)
+    for e in (big, lo, hi, o):
+        e.reset()
+    for s in range(k):
+        before = big.tile_values().sum(dim=(1, 2))
+        for e in (big, lo, hi):
+            e.step(None)
+        o.step(None)
+        after = big.tile_values().sum(dim=(1, 2))
+        cont = (big.terminated == 0)
+        delta = (after - before)[cont]
+        assert bool(((delta == 2) | (delta == 4)).all()), "a legal step adds exactly one 2 or 4"
+        assert torch.equal(big.boards()[: n // 2], lo.boards()) and torch.equal(big.boards()[n // 2:], hi.boards())
+        assert np.array_equal(big.boards()[win_off:].cpu().numpy().reshape(-1, 16), o.boards)
+        assert np.array_equal(big.reward[win_off:].cpu().numpy(), o.reward)
+    assert torch.equal(big.scores()[: n // 2], lo.scores())
+    # merge-score identity: score = sum((e-1) * 2^e) - 4 * (#spawned fours) >= 0 and <= that sum
+    e = big.boards().to(torch.int64)
+    pot = torch.where(e > 0, (e - 1) * (torch.ones_like(e) << e), torch.zeros_like(e)).sum(dim=(1, 2))
+    sc = big.scores().to(torch.int64)
+    assert bool((sc <= pot).all()) and bool(((pot - sc) % 4 == 0).all())
+
+
+def test_masked_reset_set_state_and_views(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    n = 777
+    e = Batched2048(n, seed=1)
+    e.reset()
+    for _ in range(10):
+        e.step(None)
+    before = e.get_boards().copy()
+    scores_before = e.get_scores().copy()
+    mask = torch.zeros(n, dtype=torch.uint8)
+    mask[::3] = 1
+    e.reset(mask=mask)
+    after = e.get_boards()
+    keep = mask.numpy() == 0
+    assert np.array_equal(after[keep], before[keep]) and np.array_equal(e.get_scores()[keep], scores_before[keep])
+    assert ((after[~keep] != 0).sum(axis=(1, 2)) == 2).all() and (e.get_scores()[~keep] == 0).all()
+    # zero-copy views alias engine memory
+    v = e.boards()
+    assert v.data_ptr() == e._lib.g2048_boards_ptr(e._h) and np.array_equal(v.cpu().numpy(), after)
+    # checkpoint / resume reproduces the continuation exactly
+    state = e.state_dict()
+    for _ in range(5):
+        e.step(None)
+    ref_boards, ref_scores, ref_clock = e.get_boards(), e.get_scores(), e.clock
+    f = Batched2048(n, seed=999)
+    f.load_state_dict(state)
+    for _ in range(5):
+        f.step(None)
+    assert np.array_equal(f.get_boards(), ref_boards) and np.array_equal(f.get_scores(), ref_scores)
+    assert f.clock == ref_clock
+
+
+def test_single_env_compat_matches_reference_trajectory(torch_cuda):
+    """Game2048Env (N = 1 view) driven like the reference loop reproduces the golden trajectory of
+    board 0 (seed 42), including the types the reference's tests check."""
+    from gym2048_amd import Game2048Env
+    d = load_golden("traj_random_seed42")
+    env = Game2048Env()
+    obs, info = env.reset(seed=42)
+    assert obs.shape == (16, 4, 4) and info == {}
+    vals = lambda e: np.where(e > 0, 1 << e.astype(np.int64), 0).reshape(4, 4)  # noqa: E731
+    assert np.array_equal(env.get_board(), vals(d["initial_boards"][0]))
+    for s in range(128):
+        obs, reward, terminated, truncated, info = env.step(int(d["actions"][0, s]))
+        assert isinstance(reward, float) and isinstance(terminated, bool) and truncated is False
+        assert reward == d["reward"][0, s] and terminated == bool(d["terminated"][0, s])
+        assert info["illegal_move"] == bool(d["illegal"][0, s]) and info["highest"] == 1 << int(d["highest"][0, s])
+        assert np.array_equal(env.get_board(), vals(d["terminal_boards"][0, s]))
+        assert obs.sum(axis=0).max() <= 1 and set(np.unique(obs)) <= {0, 1}
+        if terminated:
+            env.reset()
+        assert np.array_equal(env.get_board(), vals(d["boards"][0, s]))
+        assert env.score == d["score"][0, s]

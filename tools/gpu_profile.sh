@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root:  bash tools/gpu_profile.sh <tag> [bench args...]
+# Collects, under gpurun_out/prof_<tag>/:  kernel-trace stats, then PMC passes (each in its own run,
+# --kernel-trace only, as the node policy requires), and a text summary of all of them.
+set -u
+TAG=${1:-run}; shift || true
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+BENCH="python bench.py --steps 200 --warmup 20 --no-extras $*"
+rocprofv3 --kernel-trace --stats -d $O/stats -o r -- $BENCH > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/pmc_sq1 -o r -- $BENCH > $O/pmc_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $O/pmc_sq2 -o r -- $BENCH > $O/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- $BENCH > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- $BENCH > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_tcc -o r -- $BENCH > $O/pmc_tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_DRAM_32B -d $O/pmc_rd32 -o r -- $BENCH > $O/pmc_rd32.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_WRITE_DRAM_32B -d $O/pmc_wr32 -o r -- $BENCH > $O/pmc_wr32.log 2>&1
+python tools/rocpd_summary.py $O/stats/r_results.db $O/pmc_sq1/r_results.db $O/pmc_sq2/r_results.db $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_tcc/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > $O/summary.txt 2>&1
+python tools/rocpd_summary.py --traffic-json $O/traffic.json $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > /dev/null 2>&1
+grep -h '"metric"' $O/stats.log > $O/bench_under_rocprof.json
+rm -rf $O/*/r_results.db   # keep the merged gpurun_out small; the summary is what gets committed
+cat $O/summary.txt
