@@ -1,0 +1,63 @@
+"""CPU, world_size = 2 over gloo: the multi-GPU layout (one process per shard, global-index RNG, one
+all-gather of episodic returns per rollout) with the oracle standing in for the per-rank engine.
+On the GPU box the same sharding helpers run over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_global, steps, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    from gym2048_amd.sharding import allgather_returns, allreduce_summary, shard_range
+    from oracle import OracleBatch
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        shard = shard_range(n_global, rank, world)
+        ob = OracleBatch(shard.n_local, seed, board_offset=shard.offset)
+        ob.reset()
+        for _ in range(steps):
+            ob.step(None)
+        returns = allgather_returns(torch.from_numpy(ob.last_score.copy()), shard)
+        boards = allgather_returns(torch.from_numpy(ob.boards.astype(np.int32).sum(axis=1).astype(np.int32)), shard)
+        summ = allreduce_summary(int(ob.ep_count.sum()), int(ob.last_score.sum()), int(ob.last_score.max()), "cpu")
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "gathered.npz"), returns=returns.numpy(), boards=boards.numpy(),
+                     episodes=summ["episodes"], max_score=summ["max_score"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global", [4096, 1001])   # equal shards and ragged shards
+def test_two_rank_shards_equal_single_process(tmp_path, n_global):
+    from oracle import OracleBatch
+    steps, seed, world = 40, 42, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_global, steps, seed, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "gathered.npz")
+    ref = OracleBatch(n_global, seed)
+    ref.reset()
+    for _ in range(steps):
+        ref.step(None)
+    assert np.array_equal(got["returns"], ref.last_score)                      # global order, bit-exact
+    assert np.array_equal(got["boards"], ref.boards.astype(np.int32).sum(axis=1))
+    assert int(got["episodes"]) == int(ref.ep_count.sum()) and int(got["max_score"]) == int(ref.last_score.max())
+
+
+def test_allgather_single_process_is_identity():
+    from gym2048_amd.sharding import allgather_returns, shard_range
+    x = torch.arange(10, dtype=torch.int32)
+    y = allgather_returns(x, shard_range(10, 0, 1))
+    assert torch.equal(x, y) and y.data_ptr() != x.data_ptr()

@@ -315,3 +315,26 @@ def test_single_env_compat_matches_reference_trajectory(torch_cuda):
             env.reset()
         assert np.array_equal(env.get_board(), vals(d["boards"][0, s]))
         assert env.score == d["score"][0, s]
+
+
+def test_vec_env_adapter_matches_oracle_backed_adapter(torch_cuda):
+    """Vec2048 over the real engine == Vec2048 over the oracle-backed fake (obs, rewards, dones, infos)."""
+    from fake_engine import OracleEngine
+    from gym2048_amd import Vec2048
+    n, seed = 512, 17
+    real = Vec2048(n, seed=seed, illegal_move_reward=-1.0)
+    fake = Vec2048(n, seed=seed, illegal_move_reward=-1.0, engine=OracleEngine(n, seed))
+    assert np.array_equal(real.reset(), fake.reset())
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        a = rng.integers(0, 4, n)
+        o1, r1, d1, i1 = real.step(a)
+        o2, r2, d2, i2 = fake.step(a)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+        for x, y in zip(i1, i2):
+            assert set(x) == set(y)
+            if x:
+                assert x["episode"]["r"] == y["episode"]["r"] and x["episode"]["l"] == y["episode"]["l"]
+                assert x["highest"] == y["highest"] and x["illegal_move"] == y["illegal_move"]
+                assert np.array_equal(x["terminal_observation"], y["terminal_observation"])
+    assert real.render().shape == (280, 280, 3)
