@@ -143,7 +143,9 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     const size_t off_score = off_boards + align_up(n * 16);
     const size_t off_last_score = off_score + align_up(n * 4);
     const size_t off_wave_stats = off_last_score + align_up(n * 4);
-    const size_t off_stats = off_wave_stats + align_up(((n + 63) / 64) * sizeof(g2048::WaveStats));
+    // one slot per wavefront of the launch grid (whole 256-lane blocks)
+    const size_t n_slots = ((n + 255) / 256) * 4;
+    const size_t off_stats = off_wave_stats + align_up(n_slots * sizeof(g2048::WaveStats));
     e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
     err = hipMalloc(&e->slab, e->slab_bytes);
     if (err != hipSuccess) {
@@ -191,7 +193,7 @@ int g2048_seed(g2048_engine *e, uint64_t seed)
     // episode statistics restart with the stream
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(hipMemset(e->st.last_score, 0, e->n * 4));
-    G2048_HIP(hipMemset(e->st.wave_stats, 0, ((e->n + 63) / 64) * sizeof(g2048::WaveStats)));
+    G2048_HIP(hipMemset(e->st.wave_stats, 0, ((e->n + 255) / 256) * 4 * sizeof(g2048::WaveStats)));
     return G2048_OK;
 }
 

@@ -37,12 +37,27 @@ static inline uint32_t g2048_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 }
 static inline uint32_t g2048_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline uint32_t g2048_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+static inline uint32_t g2048_opaque(uint32_t x) { return x; }
+static inline uint32_t g2048_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+static inline bool g2048_any(bool x) { return x; }
 #else
 #include <hip/hip_runtime.h>
 #define G2048_DEV __device__ __forceinline__
 G2048_DEV uint32_t g2048_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 G2048_DEV uint32_t g2048_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 G2048_DEV uint32_t g2048_popc(uint32_t x) { return (uint32_t)__popc(x); }
+// Hides a value's origin from the optimizer.  Used on lane-wide select masks: without it LLVM turns
+// "(m & a) | (~m & b)" with m = -(cond) back into v_cndmask_b32_e64 (4 issue cycles) instead of one
+// v_bitop3_b32 (2 cycles).
+G2048_DEV uint32_t g2048_opaque(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// (m & a) | (~m & b) as ONE v_bitop3_b32 (2 issue cycles; v_bfi_b32 / v_cndmask_e64 take 4).
+G2048_DEV uint32_t g2048_bfi(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
+// true when the predicate holds in any active lane of the wavefront (wave-uniform).
+G2048_DEV bool g2048_any(bool x) { return __ballot(x) != 0ull; }
 #endif
 
 namespace g2048 {
@@ -92,7 +107,7 @@ G2048_DEV uint32_t z80(uint32_t x) { return ~(x + kLow7) & kHigh1; }
 // 0x80 flags -> 0x7f byte masks (enough to select bytes < 0x80).
 G2048_DEV uint32_t mask7(uint32_t f80) { return f80 - (f80 >> 7); }
 // (m & a) | (~m & b)
-G2048_DEV uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+G2048_DEV uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return g2048_bfi(m, a, b); }
 
 // 4x4 byte transpose: rows -> columns (and back; it is an involution).
 G2048_DEV Board transpose(const Board &b)
@@ -109,82 +124,80 @@ G2048_DEV Board transpose(const Board &b)
     return t;
 }
 
-// if a byte of x is zero, pull the byte of y into it (and clear it in y): one bubble step of the
-// stable "zeros to the back" compaction (game2048_env.py:249-251 skips zeros).
-G2048_DEV void pull(uint32_t &x, uint32_t &y)
-{
-    const uint32_t keep = mask7(nz80(x));
-    x = bfi(keep, x, y);
-    y &= keep;
-}
+// 0x7f in every non-zero byte (a byte-select mask; all data bytes are < 0x80).
+G2048_DEV uint32_t nzmask(uint32_t x) { return mask7(nz80(x)); }
+// all-ones when cond, else 0 (lane-wide select mask; selects then cost one v_bitop3 each).
+G2048_DEV uint32_t lanemask(bool cond) { return g2048_opaque(0u - (cond ? 1u : 0u)); }
+// the same from bit 0 of an integer, without a compare
+G2048_DEV uint32_t lanemask_bit0(uint32_t x) { return g2048_opaque(0u - (x & 1u)); }
 
 // game2048_env.py:243-260 for four lines at once.  a,b,c,d: 1st..4th cell of each line.
 // Returns the summed merge score of the four lines.
+//
+// Issue-cost notes (measured on gfx950, tools/ubench/valu_ubench.hip): VOP2 integer ops and
+// v_bitop3_b32 issue in 2 cycles, v_perm / v_bcnt / v_cndmask_e64 / multiplies in 4.  Everything
+// below is therefore phrased as three-input boolean functions of byte masks.
 G2048_DEV uint32_t shift4(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
 {
-    // -- compaction (odd-even bubble, 6 steps)
-    pull(a, b);
-    pull(c, d);
-    pull(b, c);
-    pull(a, b);
-    pull(c, d);
-    pull(b, c);
-    // -- merge flags: a pair merges when equal and non-zero; leftmost first, each cell once
-    const uint32_t eab = z80(a ^ b) & nz80(a);
-    const uint32_t ebc = z80(b ^ c) & nz80(b) & ~eab;
-    const uint32_t ecd = z80(c ^ d) & nz80(c) & ~ebc;
-    const uint32_t iab = eab >> 7, ibc = ebc >> 7, icd = ecd >> 7; // +1 on the exponent
+    // -- compaction by rank (game2048_env.py:249-251 skips zeros): the j-th output is the j-th
+    //    non-zero cell.  ka/kb/kc = "cell is non-zero" byte masks.
+    const uint32_t ka = nzmask(a), kb = nzmask(b), kc = nzmask(c);
+    const uint32_t one_ab = ka ^ kb;                                  // exactly one of a,b
+    const uint32_t all_abc = ka & kb & kc;
+    const uint32_t one_abc = (ka ^ kb ^ kc) & ~all_abc;               // exactly one of a,b,c
+    const uint32_t two_abc = ((ka & kb) | (kc & (ka | kb))) & ~all_abc; // exactly two of a,b,c
+    const uint32_t p0 = bfi(ka, a, bfi(kb, b, bfi(kc, c, d)));        // first non-zero
+    const uint32_t p1 = (b & ka) | (c & one_ab) | (d & one_abc);      // second
+    const uint32_t p2 = (c & ka & kb) | (d & two_abc);                // third
+    const uint32_t p3 = d & all_abc;                                  // fourth
+    // -- merge flags (0x80 per byte): a pair merges when equal and non-zero; leftmost first, each
+    //    cell once (:252-255).  After compaction p[j+1] != 0 implies p[j] != 0.
+    const uint32_t s1 = p1 + kLow7, s2 = p2 + kLow7, s3 = p3 + kLow7; // bit 7 = non-zero
+    const uint32_t eab = ~((p0 ^ p1) + kLow7) & s1 & kHigh1;
+    const uint32_t ebc = ~((p1 ^ p2) + kLow7) & s2 & kHigh1 & ~eab;
+    const uint32_t ecd = ~((p2 ^ p3) + kLow7) & s3 & kHigh1 & ~ebc;
+    const uint32_t iab = eab >> 7, ibc = ebc >> 7, icd = ecd >> 7;    // +1 on the exponent
     const uint32_t mab = eab - iab, mbc = ebc - ibc, mcd = ecd - icd; // 0x7f masks
-    const uint32_t a1 = a + iab, b1 = b + ibc, c1 = c + icd;
+    const uint32_t a1 = p0 + iab, b1 = p1 + ibc, c1 = p2 + icd;
     // -- outputs
-    const uint32_t o0 = a1;
-    const uint32_t o1 = bfi(mab, c1, b1);
-    const uint32_t o2 = bfi(mab, d & ~mcd, bfi(mbc, d, c1));
-    const uint32_t o3 = d & ~(mab | mbc | mcd);
-    // -- score: sum of 2^e over the merged cells (game2048_env.py:253-254)
-    const uint32_t m1 = (a1 & mab) | (b1 & mbc); // first merge of each line (0 if none)
-    const uint32_t m2 = c1 & mcd;                // second merge of each line
-    uint32_t score = 0;
+    a = a1;
+    b = bfi(mab, c1, b1);
+    c = bfi(mab, p3 & ~mcd, bfi(mbc, p3, c1));
+    d = p3 & ~(mab | mbc | mcd);
+    // -- score: sum of 2^e over the merged cells (:253-254).  v_lshlrev uses only the low five bits
+    //    of the shift operand, so "1 << (x >> 8l)" needs no byte extraction; bytes without a merge
+    //    are set to 31, whose 2^31 terms can only disturb bit 31, which the final mask drops.
+    const uint32_t m1 = bfi(mab, a1, bfi(mbc, b1, 0x1f1f1f1fu)); // first merge of each line
+    const uint32_t m2 = bfi(mcd, c1, 0x1f1f1f1fu);               // second merge of each line
+    uint32_t score = (1u << (m1 & 31u)) + (1u << (m2 & 31u));
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        score += 1u << ((m1 >> (8 * l)) & 0xff);
-        score += 1u << ((m2 >> (8 * l)) & 0xff);
-    }
-    score -= 8u - g2048_popc(eab | ebc) - g2048_popc(ecd); // the "1 << 0" of non-merged bytes
-    a = o0;
-    b = o1;
-    c = o2;
-    d = o3;
-    return score;
+    for (int l = 1; l < 4; ++l)
+        score += (1u << ((m1 >> (8 * l)) & 31u)) + (1u << ((m2 >> (8 * l)) & 31u));
+    return score & 0x7fffffffu;
 }
 
 // game2048_env.py:194-241.  Returns true when the board changed (false = IllegalMove).
 G2048_DEV bool move(Board &bd, uint32_t action, uint32_t &score)
 {
-    const bool horizontal = (action & 1u) != 0;          // :211 dir_mod_two
-    const bool reversed = ((action ^ (action >> 1)) & 1u) != 0; // :212 shift_direction
+    const uint32_t hz = lanemask_bit0(action);                 // :211 dir_mod_two
+    const uint32_t rv = lanemask_bit0(action ^ (action >> 1)); // :212 shift_direction
     const Board t = transpose(bd);
-    uint32_t l0 = horizontal ? t.r[0] : bd.r[0];
-    uint32_t l1 = horizontal ? t.r[1] : bd.r[1];
-    uint32_t l2 = horizontal ? t.r[2] : bd.r[2];
-    uint32_t l3 = horizontal ? t.r[3] : bd.r[3];
-    uint32_t a = reversed ? l3 : l0;
-    uint32_t b = reversed ? l2 : l1;
-    uint32_t c = reversed ? l1 : l2;
-    uint32_t d = reversed ? l0 : l3;
+    const uint32_t l0 = bfi(hz, t.r[0], bd.r[0]), l1 = bfi(hz, t.r[1], bd.r[1]);
+    const uint32_t l2 = bfi(hz, t.r[2], bd.r[2]), l3 = bfi(hz, t.r[3], bd.r[3]);
+    uint32_t a = bfi(rv, l3, l0), b = bfi(rv, l2, l1), c = bfi(rv, l1, l2), d = bfi(rv, l0, l3);
     const uint32_t a0 = a, b0 = b, c0 = c, d0 = d;
     score = shift4(a, b, c, d);
     const bool changed = ((a ^ a0) | (b ^ b0) | (c ^ c0) | (d ^ d0)) != 0; // :222,234,238
     Board o;
-    o.r[0] = reversed ? d : a;
-    o.r[1] = reversed ? c : b;
-    o.r[2] = reversed ? b : c;
-    o.r[3] = reversed ? a : d;
+    o.r[0] = bfi(rv, d, a);
+    o.r[1] = bfi(rv, c, b);
+    o.r[2] = bfi(rv, b, c);
+    o.r[3] = bfi(rv, a, d);
     const Board ot = transpose(o);
-    bd.r[0] = horizontal ? ot.r[0] : o.r[0];
-    bd.r[1] = horizontal ? ot.r[1] : o.r[1];
-    bd.r[2] = horizontal ? ot.r[2] : o.r[2];
-    bd.r[3] = horizontal ? ot.r[3] : o.r[3];
+    bd.r[0] = bfi(hz, ot.r[0], o.r[0]);
+    bd.r[1] = bfi(hz, ot.r[1], o.r[1]);
+    bd.r[2] = bfi(hz, ot.r[2], o.r[2]);
+    bd.r[3] = bfi(hz, ot.r[3], o.r[3]);
     return changed;
 }
 
@@ -196,41 +209,49 @@ G2048_DEV uint32_t count_empty(const Board &bd)
 
 // game2048_env.py:166-176 with the injected spawn word w: value 2 (exp 1) if (w & 0xffff) <= 58982
 // else 4 (exp 2); position = k-th empty cell in row-major order, k = (w * n_empty) >> 32.
-// Precondition: at least one empty cell.
-G2048_DEV void add_tile(Board &bd, uint32_t w)
+// `enable` (all-ones / 0) gates the write.  Returns the number of empty cells BEFORE the spawn.
+G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable = 0xffffffffu)
 {
     const uint32_t z0 = z80(bd.r[0]), z1 = z80(bd.r[1]), z2 = z80(bd.r[2]), z3 = z80(bd.r[3]);
     const uint32_t c0 = g2048_popc(z0), c1 = c0 + g2048_popc(z1), c2 = c1 + g2048_popc(z2),
                    n = c2 + g2048_popc(z3);
     const uint32_t k = g2048_mulhi(w, n);
-    const bool g0 = k >= c0, g1 = k >= c1, g2 = k >= c2;
-    const uint32_t zs = g2 ? z3 : (g1 ? z2 : (g0 ? z1 : z0));  // empty flags of the chosen row
-    const uint32_t kk = k - (g2 ? c2 : (g1 ? c1 : (g0 ? c0 : 0u))); // rank inside the row
-    const uint32_t p0 = g2048_popc(zs & 0x00000080u), p1 = g2048_popc(zs & 0x00008080u),
-                   p2 = g2048_popc(zs & 0x00808080u);
-    const uint32_t col = (p0 <= kk) + (p1 <= kk) + (p2 <= kk);
-    const uint32_t exp = ((w & 0xffffu) <= 58982u) ? 1u : 2u;
-    const uint32_t tile = exp << (8u * col);
-    bd.r[0] |= g0 ? 0u : tile;
-    bd.r[1] |= (g0 && !g1) ? tile : 0u;
-    bd.r[2] |= (g1 && !g2) ? tile : 0u;
-    bd.r[3] |= g2 ? tile : 0u;
+    // row of the k-th empty cell: g_i = all-ones when k >= c_i (nested: g2 implies g1 implies g0)
+    const uint32_t g0 = (uint32_t)((int32_t)(c0 - 1u - k) >> 31), g1 = (uint32_t)((int32_t)(c1 - 1u - k) >> 31),
+                   g2 = (uint32_t)((int32_t)(c2 - 1u - k) >> 31);
+    const uint32_t zs = bfi(g2, z3, bfi(g1, z2, bfi(g0, z1, z0)));     // empty flags of that row
+    const uint32_t base = bfi(g2, c2, bfi(g1, c1, c0 & g0));           // empties before that row
+    // inside the row: inclusive prefix count of the empty flags per byte; the target byte is the
+    // empty one whose count equals kk + 1
+    const uint32_t want = (k - base + 1u) * 0x01010101u;
+    const uint32_t prefix = (zs >> 7) * 0x01010101u;
+    const uint32_t hit = ~((prefix ^ want) + kLow7) & zs;              // 0x80 at the chosen cell only
+    // exponent 1 -> 0x01 at that byte (hit >> 7), exponent 2 -> 0x02 (hit >> 6)
+    const uint32_t tile = (hit >> (((w & 0xffffu) <= 58982u) ? 7u : 6u)) & enable;
+    bd.r[0] |= tile & ~g0;
+    bd.r[1] |= tile & g0 & ~g1;
+    bd.r[2] |= tile & g1 & ~g2;
+    bd.r[3] |= tile & g2;
+    return n;
 }
 
 // game2048_env.py:102-111: empty board + two spawns from words w1, w2.
 G2048_DEV Board fresh_board(uint32_t w1, uint32_t w2)
 {
-    const uint32_t p1 = w1 >> 28;                 // (w1 * 16) >> 32
+    const uint32_t p1 = w1 >> 28;                  // (w1 * 16) >> 32: cell of the first tile
     const uint32_t k2 = g2048_mulhi(w2, 15u);
     const uint32_t p2 = k2 + (k2 >= p1 ? 1u : 0u); // k2-th empty cell, skipping p1
     const uint32_t e1 = ((w1 & 0xffffu) <= 58982u) ? 1u : 2u;
     const uint32_t e2 = ((w2 & 0xffffu) <= 58982u) ? 1u : 2u;
-    const uint32_t t1 = e1 << (8u * (p1 & 3u)), t2 = e2 << (8u * (p2 & 3u));
-    const uint32_t q1 = p1 >> 2, q2 = p2 >> 2;
+    // place each exponent in a 64-bit half (cells 0-7 / 8-15) with one 64-bit shift
+    const uint64_t x1 = (uint64_t)e1 << (8u * (p1 & 7u)), x2 = (uint64_t)e2 << (8u * (p2 & 7u));
+    const uint32_t h1 = lanemask_bit0(p1 >> 3), h2 = lanemask_bit0(p2 >> 3); // upper half?
+    const uint32_t x1l = (uint32_t)x1, x1h = (uint32_t)(x1 >> 32), x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
     Board bd;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i)
-        bd.r[i] = (q1 == i ? t1 : 0u) | (q2 == i ? t2 : 0u);
+    bd.r[0] = (x1l & ~h1) | (x2l & ~h2);
+    bd.r[1] = (x1h & ~h1) | (x2h & ~h2);
+    bd.r[2] = (x1l & h1) | (x2l & h2);
+    bd.r[3] = (x1h & h1) | (x2h & h2);
     return bd;
 }
 
@@ -298,25 +319,33 @@ G2048_DEV StepResult step_env(Board &bd, int32_t &score, uint32_t action, const 
                               uint32_t max_exp, bool auto_reset)
 {
     StepResult r;
-    Board nb = bd;
     uint32_t gain;
-    const bool legal = move(nb, action, gain);            // :85
-    // add_tile needs an empty cell; a board that changed always has one (a full board can only
-    // change by merging).  When the move was illegal the result is dropped.
-    add_tile(nb, w.w[0]);                                 // :88
-    const bool end = is_end(nb, max_exp);                 // :89
+    const bool legal = move(bd, action, gain);            // :85 (an illegal move leaves bd unchanged
+                                                          //      and merges nothing: gain == 0)
+    // :88 add_tile needs an empty cell; a board that changed always has one (a full board can only
+    // change by merging).  After an illegal move nothing is spawned (:91-95).
+    const uint32_t n_empty = add_tile(bd, w.w[0], lanemask(legal));
+    // :89 isend(): the board is full after the spawn exactly when it had one empty cell before it
+    bool end = false;
+    if (n_empty == 1u)                                    // :270-271
+        end = !has_equal_neighbours(bd);                  // :273-280
+    if (max_exp != 0 && highest(bd) == max_exp)           // :267-268
+        end = true;
     r.illegal = !legal;                                   // :91-95
     r.terminated = legal ? end : true;
     r.reward = legal ? (float)gain : illegal_reward;      // :90 / :95
-    if (legal) {
-        bd = nb;
-        score += (int32_t)gain;                           // :86
-    }
+    score += (int32_t)gain;                               // :86
     r.terminal = bd;
     r.terminal_score = score;
-    if (r.terminated && auto_reset) {
-        bd = fresh_board(legal ? w.w[1] : w.w[0], legal ? w.w[2] : w.w[1]); // :104,:108-109
-        score = 0;                                        // :105
+    const bool do_reset = r.terminated && auto_reset;
+    if (g2048_any(do_reset)) {                            // wave-uniform: skipped when nobody finished
+        const uint32_t lm = lanemask(legal), rm = lanemask(do_reset);
+        const Board fb = fresh_board(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1])); // :104,:108-109
+        bd.r[0] = bfi(rm, fb.r[0], bd.r[0]);
+        bd.r[1] = bfi(rm, fb.r[1], bd.r[1]);
+        bd.r[2] = bfi(rm, fb.r[2], bd.r[2]);
+        bd.r[3] = bfi(rm, fb.r[3], bd.r[3]);
+        score &= (int32_t)~rm;                            // :105
     }
     return r;
 }

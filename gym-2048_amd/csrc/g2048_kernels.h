@@ -8,9 +8,9 @@
 namespace g2048 {
 
 // Per-wavefront episode accumulators: the only episode bookkeeping the hot kernel touches besides
-// last_score.  One slot per 64 boards, updated by lane 0 with fire-and-forget atomics, so a step
+// last_score.  One slot per 64 boards, private to the wave that owns them (plain load-add-store by lane 0), so a step
 // adds no per-board read-modify-write traffic.
-struct WaveStats {
+struct alignas(8) WaveStats {
     unsigned int episodes;        // finished episodes
     unsigned int illegal_ends;    // ... of which ended on an illegal move
     unsigned long long score_sum; // sum of final merge scores

@@ -35,10 +35,37 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
 // Episode bookkeeping.  Boards that ended an episode write their final score (and, if asked, their
 // terminal board); the wave's totals go to its WaveStats slot.  The whole block is skipped by a
 // wave-uniform branch when no lane terminated.
+// Wave-wide sum and max of a non-negative per-lane value, result valid in lane 63.  Seven DPP steps
+// each (row_shr 1,2,3,4,8 then row_bcast 15, 31): pure VALU, no LDS, no scalar loop.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_shift(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+
+__device__ __forceinline__ void wave_sum_max(int v, int &sum, int &mx)
+{
+    int s = v + dpp_shift<0x111, 0xf, 0xf>(v) + dpp_shift<0x112, 0xf, 0xf>(v) + dpp_shift<0x113, 0xf, 0xf>(v);
+    int m = max(max(v, dpp_shift<0x111, 0xf, 0xf>(v)), max(dpp_shift<0x112, 0xf, 0xf>(v), dpp_shift<0x113, 0xf, 0xf>(v)));
+    s += dpp_shift<0x114, 0xf, 0xe>(s);
+    m = max(m, dpp_shift<0x114, 0xf, 0xe>(m));
+    s += dpp_shift<0x118, 0xf, 0xc>(s);
+    m = max(m, dpp_shift<0x118, 0xf, 0xc>(m));
+    s += dpp_shift<0x142, 0xa, 0xf>(s); // row_bcast:15 into rows 1 and 3
+    m = max(m, dpp_shift<0x142, 0xa, 0xf>(m));
+    s += dpp_shift<0x143, 0xc, 0xf>(s); // row_bcast:31 into rows 2 and 3
+    m = max(m, dpp_shift<0x143, 0xc, 0xf>(m));
+    sum = s;
+    mx = m;
+}
+
+// Episode bookkeeping.  Boards that ended an episode write their final score (and, if asked, their
+// terminal board); the wave's totals are accumulated in lane 63.  The whole block is skipped by a
+// wave-uniform branch when no lane terminated.
 struct WaveAcc {
     unsigned int episodes = 0, illegal_ends = 0;
-    unsigned long long score_sum = 0;
-    int max_score = 0;
+    unsigned long long score_sum = 0; // valid in lane 63 only
+    int max_score = 0;                // valid in lane 63 only
 };
 
 __device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, const StepResult &r, WaveAcc &acc)
@@ -53,23 +80,28 @@ __device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, c
     }
     acc.episodes += static_cast<unsigned int>(__popcll(done));
     acc.illegal_ends += static_cast<unsigned int>(__popcll(__ballot(r.terminated && r.illegal)));
-    for (unsigned long long m = done; m != 0; m &= m - 1) { // scalar walk over the few finished lanes
-        const int v = __builtin_amdgcn_readlane(r.terminal_score, __ffsll(static_cast<long long>(m)) - 1);
-        acc.score_sum += static_cast<unsigned long long>(static_cast<long long>(v));
-        acc.max_score = max(acc.max_score, v);
-    }
+    int sum, mx;
+    wave_sum_max(r.terminated ? r.terminal_score : 0, sum, mx);
+    acc.score_sum += static_cast<unsigned long long>(static_cast<long long>(sum));
+    acc.max_score = max(acc.max_score, mx);
 }
 
-__device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, const WaveAcc &acc)
+// The wave's slot is private to it (one wave per slot per launch, launches are stream-ordered), so
+// the accumulators are updated with a plain load-add-store by ONE lane (63, where the DPP
+// reductions land).  `old` is loaded at kernel entry, together with the board, so its latency is
+// never exposed.  Requires full wavefronts: the launchers pad the tail wave's bookkeeping by
+// running it with all 64 lanes active (boards beyond n are never touched).
+__device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, const WaveStats &old, const WaveAcc &acc)
 {
-    if (acc.episodes == 0 || (threadIdx.x & 63u) != 0)
+    if (acc.episodes == 0 || (threadIdx.x & 63u) != 63u)
         return;
-    WaveStats *ws = p.st.wave_stats + (i >> 6);
-    atomicAdd(&ws->episodes, acc.episodes);
-    if (acc.illegal_ends)
-        atomicAdd(&ws->illegal_ends, acc.illegal_ends);
-    atomicAdd(&ws->score_sum, acc.score_sum);
-    atomicMax(&ws->max_score, acc.max_score);
+    WaveStats ws;
+    ws.episodes = old.episodes + acc.episodes;
+    ws.illegal_ends = old.illegal_ends + acc.illegal_ends;
+    ws.score_sum = old.score_sum + acc.score_sum;
+    ws.max_score = max(old.max_score, acc.max_score);
+    ws.pad = 0;
+    p.st.wave_stats[i >> 6] = ws;
 }
 
 // ---------------------------------------------------------------------------------- step
@@ -83,40 +115,46 @@ __device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, 
 template <int ACT>
 __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= p.n)
-        return;
+    // Lanes past the end stay active (the DPP reductions and the lane-63 flush need whole
+    // wavefronts): they recompute board n-1 and write nothing.
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
     const uint4 v = p.st.boards[i];
     Board bd{{v.x, v.y, v.z, v.w}};
     int32_t score = p.st.score[i];
+    const WaveStats old_stats = p.st.wave_stats[i_raw >> 6]; // same address in all lanes: one request
 
     const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
     const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
 
-    const StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+    StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
 
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-    p.st.score[i] = score;
-    if (p.reward)
-        p.reward[i] = r.reward;
-    if (p.terminated)
-        p.terminated[i] = r.terminated ? 1 : 0;
-    if (p.illegal)
-        p.illegal[i] = r.illegal ? 1 : 0;
-    if (p.highest)
-        p.highest[i] = static_cast<uint8_t>(highest(r.terminal)); // :97
+    if (valid) {
+        p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+        p.st.score[i] = score;
+        if (p.reward)
+            p.reward[i] = r.reward;
+        if (p.terminated)
+            p.terminated[i] = r.terminated ? 1 : 0;
+        if (p.illegal)
+            p.illegal[i] = r.illegal ? 1 : 0;
+        if (p.highest)
+            p.highest[i] = static_cast<uint8_t>(highest(r.terminal)); // :97
+    }
+    r.terminated = r.terminated && valid;
     WaveAcc acc;
     record_episodes(p, i, r, acc);
-    flush_wave_stats(p, i, acc);
+    flush_wave_stats(p, i_raw, old_stats, acc);
 }
 
 // ------------------------------------------------------------------------- fused rollout
 // k steps of the synthetic random policy in ONE launch; the board never leaves registers.
 __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= p.n)
-        return;
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
     const uint4 v = p.st.boards[i];
     Board bd{{v.x, v.y, v.z, v.w}};
     int32_t score = p.st.score[i];
@@ -125,12 +163,15 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
                                       p.seed_lo, p.seed_hi);
-        const StepResult r = step_env(bd, score, w.w[3] >> 30, w, p.illegal_reward, p.max_exp, true);
+        StepResult r = step_env(bd, score, w.w[3] >> 30, w, p.illegal_reward, p.max_exp, true);
+        r.terminated = r.terminated && valid;
         record_episodes(p, i, r, acc);
     }
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-    p.st.score[i] = score;
-    flush_wave_stats(p, i, acc);
+    if (valid) {
+        p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+        p.st.score[i] = score;
+    }
+    flush_wave_stats(p, i_raw, p.st.wave_stats[i_raw >> 6], acc);
 }
 
 // ---------------------------------------------------------------------------------- reset

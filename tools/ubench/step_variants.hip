@@ -9,9 +9,11 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../gym-2048_amd/csrc/g2048_device.h"
+#include "../../gym-2048_amd/csrc/g2048_kernels.hip" // the product kernels themselves (variant "prod")
 
 using namespace g2048;
+static StepArgs g_prod;   // product-kernel arguments, filled in main()
+static int g_prod_outputs = 1;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -111,8 +113,10 @@ __global__ void init_boards(uint4 *boards, int32_t *score, uint8_t *actions, uin
 }
 
 struct Variant { const char *name; void (*launch)(const Args &, uint32_t blocks); uint32_t blocks; };
+static uint32_t g_lds = 0;
 
-template <int FLAGS> void launch(const Args &a, uint32_t blocks) { hipLaunchKernelGGL(kern<FLAGS>, dim3(blocks), dim3(256), 0, 0, a); }
+template <int FLAGS> void launch(const Args &a, uint32_t blocks) { hipLaunchKernelGGL(kern<FLAGS>, dim3(blocks), dim3(256), g_lds, 0, a); }
+template <int FLAGS, int LDS> void launch_lds(const Args &a, uint32_t blocks) { hipLaunchKernelGGL(kern<FLAGS>, dim3(blocks), dim3(256), LDS, 0, a); }
 
 int main(int argc, char **argv)
 {
@@ -145,11 +149,35 @@ int main(int argc, char **argv)
         {"v7 memory only (no compute)", launch<F_SCORE | F_STORE>, full},
         {"v7b memory only, pipelined 2048", launch<F_SCORE | F_STORE | F_PIPE>, 2048},
         {"v8 no score, no record, pipelined 2048", launch<F_COMPUTE | F_STORE | F_PIPE>, 2048},
+        {"v10a full, LDS cap 4 blocks/CU", launch_lds<ALL | F_IDX64, 40000>, full},
+        {"v10b full, LDS cap 5 blocks/CU", launch_lds<ALL | F_IDX64, 32000>, full},
+        {"v10c full, LDS cap 6 blocks/CU", launch_lds<ALL | F_IDX64, 26000>, full},
+        {"v10d full, LDS cap 3 blocks/CU", launch_lds<ALL | F_IDX64, 53000>, full},
+        {"v10e full, LDS cap 2 blocks/CU", launch_lds<ALL | F_IDX64, 80000>, full},
+        {"v10f compute only, LDS cap 4 blocks/CU", launch_lds<F_COMPUTE | F_SCORE, 40000>, full},
+        {"v10g compute only, LDS cap 2 blocks/CU", launch_lds<F_COMPUTE | F_SCORE, 80000>, full},
         {"v9a full, prio (blk>>8)&3", launch<ALL | F_PRIO8>, full},
         {"v9b full, prio (blk>>11)&3", launch<ALL | F_PRIO11>, full},
         {"v9c full, prio blk&3", launch<ALL | F_PRIOW>, full},
         {"v9d compute only, prio (blk>>8)&3", launch<F_COMPUTE | F_SCORE | F_PRIO8>, full},
     };
+    // the product kernel through its own launcher
+    {
+        g_prod = StepArgs{};
+        g_prod.st.boards = a.boards; g_prod.st.score = a.score; g_prod.st.last_score = a.last_score;
+        CHECK(hipMalloc(&g_prod.st.wave_stats, ((size_t)n / 64 + 4) * sizeof(WaveStats)));
+        CHECK(hipMemset(g_prod.st.wave_stats, 0, ((size_t)n / 64 + 4) * sizeof(WaveStats)));
+        g_prod.n = n; g_prod.seed_lo = 42; g_prod.auto_reset = 1;
+    }
+    vs.push_back({"prod step_kernel<1> (u8 actions, reward+terminated)", [](const Args &aj, uint32_t) {
+        StepArgs p = g_prod; p.actions = aj.actions; p.reward = aj.reward; p.terminated = aj.terminated; p.t_lo = aj.t_lo;
+        launch_step(p, 1, 0); }, full});
+    vs.push_back({"prod step_kernel<0> (synthetic actions)", [](const Args &aj, uint32_t) {
+        StepArgs p = g_prod; p.reward = aj.reward; p.terminated = aj.terminated; p.t_lo = aj.t_lo;
+        launch_step(p, 0, 0); }, full});
+    vs.push_back({"prod step_kernel<1>, no outputs", [](const Args &aj, uint32_t) {
+        StepArgs p = g_prod; p.actions = aj.actions; p.t_lo = aj.t_lo;
+        launch_step(p, 1, 0); }, full});
     std::vector<std::vector<float>> times(vs.size());
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int r = 0; r < rounds + 2; ++r) {
