@@ -128,11 +128,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU; the product has no CPU path")
+    # G2048_BENCH_BACKEND=gloo + G2048_BENCH_SAME_DEVICE=1: smoke-test the N > 1 code path on a
+    # one-GPU box (all ranks share cuda:0, collectives over gloo through host copies).
+    backend = os.environ.get("G2048_BENCH_BACKEND", "nccl")
+    if os.environ.get("G2048_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -152,6 +160,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_returns():
+        local = eng.last_scores()
+        if backend != "nccl" and world > 1:        # gloo smoke test: collectives on host copies
+            return allgather_returns(local.cpu(), shard)
+        return allgather_returns(local, shard)
+
     # ---- warm-up: W untimed steps (own small buffers), then inputs for the timed K steps
     if W > 0:
         wa = eng.random_actions(W)
@@ -163,7 +177,7 @@ def main():
     reward.zero_()
     terminated.zero_()
     if world > 1:                                        # warm the collective once (communicator setup)
-        allgather_returns(eng.last_scores(), shard)
+        gather_returns()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
@@ -171,12 +185,13 @@ def main():
     ev0.record()
     eng.rollout(actions, reward=reward, terminated=terminated)   # EXACTLY K step launches
     ev1.record()
-    gathered = allgather_returns(eng.last_scores(), shard)       # once per rollout (N > 1: RCCL)
+    gathered = gather_returns()                                  # once per rollout (N > 1: RCCL)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_region_ms = ev0.elapsed_time(ev1)
 
-    tmax = torch.tensor([elapsed, kernel_region_ms], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, kernel_region_ms], dtype=torch.float64,
+                        device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_region_ms = float(tmax[0]), float(tmax[1])
@@ -202,13 +217,13 @@ def main():
                    else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None if not traffic else traffic.get("bytes_per_launch"),
+                     "traffic": traffic.get("bytes_per_launch") if (traffic and B == (1 << 20)) else None,
                      "kernel": "g2048::step_kernel<1>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us},
         "episodes_finished": int(stats["episodes"]), "mean_episode_score": stats["mean_score"],
     }
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
         # (a) fused K-step rollout kernel: boards stay in registers; NOT HBM-bound, 38 B model n/a
         eng.rollout_random(8)

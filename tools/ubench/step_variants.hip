@@ -123,7 +123,7 @@ int main(int argc, char **argv)
     const int lg = argc > 1 ? atoi(argv[1]) : 20;
     const int rounds = argc > 2 ? atoi(argv[2]) : 30;
     const uint32_t n = 1u << lg;
-    const int K = 64; // launches per timing sample, each with its own action/reward/terminated slice
+    const int K = argc > 3 ? atoi(argv[3]) : 64; // launches per timing sample, each with its own action/reward/terminated slice
     Args a{};
     a.n = n; a.seed_lo = 42; a.seed_hi = 0; a.t_lo = 1;
     uint8_t *actions; float *reward; uint8_t *terminated;
