@@ -52,7 +52,7 @@ class Batched2048:
     """
 
     def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
-                 illegal_move_reward: float = 0.0, max_tile=None):
+                 illegal_move_reward: float = 0.0, max_tile=None, rng: str = "philox"):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         if not torch.cuda.is_available():
@@ -65,6 +65,9 @@ class Batched2048:
         check(self._lib.g2048_create(self.n_envs, self.device_index, int(seed) & (2**64 - 1), self.board_offset,
                                      C.byref(self._h)))
         self._fresh = True
+        if rng not in ("philox", "numpy"):
+            raise ValueError("rng must be 'philox' (spawn stream) or 'numpy' (the reference's own PCG64)")
+        self.rng_mode = rng
         self.illegal_move_reward = 0.0
         self.max_tile = None
         self.set_illegal_move_reward(illegal_move_reward)
@@ -77,6 +80,8 @@ class Batched2048:
         self.highest = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.terminal_boards = torch.zeros((n, 16), dtype=torch.uint8, device=dev)
         self._boards_view = None
+        if self.rng_mode == "numpy":
+            self.seed(seed)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -109,6 +114,29 @@ class Batched2048:
         """Seeding half of ``reset(seed=...)`` (game2048_env.py:103)."""
         check(self._lib.g2048_seed(self._h, int(seed) & (2**64 - 1)))
         self._fresh = True
+        if self.rng_mode == "numpy":
+            # board i <- numpy PCG64(SeedSequence(seed + global index)), as gymnasium / SB3 seed env i
+            from .seeding import pcg64_planes
+            first = int(seed) + self.board_offset
+            self.set_numpy_rng(pcg64_planes(range(first, first + self.n_envs)))
+
+    def set_numpy_rng(self, planes):
+        """Install per-board numpy PCG64 states (uint64 ``[5, n]``, see ``seeding.pcg64_planes``) and
+        switch to the numpy-compatible RNG mode; ``None`` returns to the spawn stream."""
+        if planes is None:
+            check(self._lib.g2048_set_numpy_rng(self._h, None, self._stream()))
+            self.rng_mode = "philox"
+            return
+        planes = np.ascontiguousarray(planes, dtype=np.uint64)
+        if planes.shape != (5, self.n_envs):
+            raise ValueError(f"planes must be uint64 [5, {self.n_envs}]")
+        check(self._lib.g2048_set_numpy_rng(self._h, planes.ctypes.data, self._stream()))
+        self.rng_mode = "numpy"
+
+    def get_numpy_rng(self) -> np.ndarray:
+        planes = np.empty((5, self.n_envs), np.uint64)
+        check(self._lib.g2048_get_numpy_rng(self._h, planes.ctypes.data, self._stream()))
+        return planes
 
     @property
     def clock(self) -> int:
@@ -285,14 +313,13 @@ class Batched2048:
         nbytes = self._lib.g2048_state_bytes(self._h)
         blob = np.empty(nbytes, np.uint8)
         check(self._lib.g2048_get_state(self._h, blob.ctypes.data, self._stream()))
-        return {"blob": blob, "fresh": self._fresh}
+        return {"blob": blob, "fresh": self._fresh, "rng_mode": self.rng_mode}
 
     def load_state_dict(self, state: dict):
         blob = np.ascontiguousarray(state["blob"], dtype=np.uint8)
-        if blob.size != self._lib.g2048_state_bytes(self._h):
-            raise ValueError("state blob size does not match this engine")
         check(self._lib.g2048_set_state(self._h, blob.ctypes.data, self._stream()))
         self._fresh = bool(state.get("fresh", False))
+        self.rng_mode = state.get("rng_mode", "philox")
 
     # ------------------------------------------------------------------ numpy facade (used by the
     # single-env and VecEnv adapters; tests replace this object by an oracle-backed fake)

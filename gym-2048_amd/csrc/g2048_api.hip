@@ -111,7 +111,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 2; }
+int g2048_abi_version(void) { return 3; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -175,6 +175,8 @@ int g2048_destroy(g2048_engine *e)
     hipError_t err = hipSuccess;
     if (e->slab) {
         (void)hipSetDevice(e->device);
+        if (e->st.rng)
+            (void)hipFree(e->st.rng);
         err = hipFree(e->slab);
     }
     delete e;
@@ -243,7 +245,10 @@ int g2048_reset(g2048_engine *e, int new_transaction, uint32_t first_slot, const
         e->t += 1;
     e->fresh = 0;
     const g2048::StepArgs a = make_args(e, nullptr, 0);
-    G2048_HIP(g2048::launch_reset(a, first_slot, mask, static_cast<hipStream_t>(stream)));
+    if (e->st.rng)
+        G2048_HIP(g2048::launch_reset_numpy(a, mask, static_cast<hipStream_t>(stream)));
+    else
+        G2048_HIP(g2048::launch_reset(a, first_slot, mask, static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
 
@@ -257,7 +262,10 @@ int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *s
     e->t += 1;
     e->fresh = 0;
     const g2048::StepArgs a = make_args(e, io, auto_reset);
-    G2048_HIP(g2048::launch_step(a, io->action_dtype, static_cast<hipStream_t>(stream)));
+    if (e->st.rng)
+        G2048_HIP(g2048::launch_step_numpy(a, io->action_dtype, static_cast<hipStream_t>(stream)));
+    else
+        G2048_HIP(g2048::launch_step(a, io->action_dtype, static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
 
@@ -282,7 +290,10 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         e->t += 1;
         e->fresh = 0;
         const g2048::StepArgs a = make_args(e, &s, auto_reset);
-        G2048_HIP(g2048::launch_step(a, s.action_dtype, static_cast<hipStream_t>(stream)));
+        if (e->st.rng)
+            G2048_HIP(g2048::launch_step_numpy(a, s.action_dtype, static_cast<hipStream_t>(stream)));
+        else
+            G2048_HIP(g2048::launch_step(a, s.action_dtype, static_cast<hipStream_t>(stream)));
     }
     return G2048_OK;
 }
@@ -293,6 +304,8 @@ int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream)
         return fail(G2048_ERR_INVALID, "engine is NULL");
     if (k_steps == 0)
         return G2048_OK;
+    if (e->st.rng)
+        return fail(G2048_ERR_INVALID, "g2048_rollout_random draws from the spawn stream; not available in numpy-RNG mode");
     G2048_HIP(hipSetDevice(e->device));
     e->t += 1; // transaction of the first fused step
     e->fresh = 0;
@@ -333,7 +346,10 @@ int g2048_add_tile(g2048_engine *e, uint32_t slot, void *stream)
     G2048_HIP(hipSetDevice(e->device));
     e->fresh = 0;
     const g2048::StepArgs a = make_args(e, nullptr, 0);
-    G2048_HIP(g2048::launch_add_tile(a, slot, static_cast<hipStream_t>(stream)));
+    if (e->st.rng)
+        G2048_HIP(g2048::launch_add_tile_numpy(a, static_cast<hipStream_t>(stream)));
+    else
+        G2048_HIP(g2048::launch_add_tile(a, slot, static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
 
@@ -429,18 +445,52 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     return G2048_OK;
 }
 
+int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    G2048_HIP(hipSetDevice(e->device));
+    if (!planes) { // back to the spawn stream
+        if (e->st.rng)
+            G2048_HIP(hipFree(e->st.rng));
+        e->st.rng = nullptr;
+        return G2048_OK;
+    }
+    if (!e->st.rng) {
+        void *p = nullptr;
+        hipError_t err = hipMalloc(&p, e->n * 40);
+        if (err != hipSuccess)
+            return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)(e->n * 40), hipGetErrorString(err));
+        e->st.rng = static_cast<uint64_t *>(p);
+    }
+    return copy_in(e, e->st.rng, planes, e->n * 40, stream);
+}
+
+int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream)
+{
+    if (!e || !e->st.rng)
+        return fail(G2048_ERR_INVALID, "engine is not in numpy-RNG mode");
+    return copy_out(e, planes, e->st.rng, e->n * 40, stream);
+}
+
 uint64_t g2048_state_bytes(const g2048_engine *e)
 {
-    return e ? sizeof(StateHeader) + e->slab_bytes : 0;
+    return e ? sizeof(StateHeader) + e->slab_bytes + (e->st.rng ? e->n * 40 : 0) : 0;
 }
 
 int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream)
 {
     if (!e || !host_buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
-    StateHeader h{kStateMagic, e->n, e->seed, e->board_offset, e->t, e->fresh, e->max_exp, e->illegal_reward, 0};
+    StateHeader h{kStateMagic, e->n, e->seed, e->board_offset, e->t, e->fresh, e->max_exp, e->illegal_reward,
+                  e->st.rng ? 1u : 0u};
     std::memcpy(host_buf, &h, sizeof h);
-    return copy_out(e, static_cast<char *>(host_buf) + sizeof h, e->slab, e->slab_bytes, stream);
+    char *body = static_cast<char *>(host_buf) + sizeof h;
+    if (int rc = copy_out(e, body, e->slab, e->slab_bytes, stream))
+        return rc;
+    if (e->st.rng)
+        return copy_out(e, body + e->slab_bytes, e->st.rng, e->n * 40, stream);
+    return G2048_OK;
 }
 
 int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream)
@@ -458,7 +508,12 @@ int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream)
     e->fresh = h.fresh;
     e->max_exp = h.max_exp;
     e->illegal_reward = h.illegal_reward;
-    return copy_in(e, e->slab, static_cast<const char *>(host_buf) + sizeof h, e->slab_bytes, stream);
+    const char *body = static_cast<const char *>(host_buf) + sizeof h;
+    if (int rc = copy_in(e, e->slab, body, e->slab_bytes, stream))
+        return rc;
+    if (h.reserved) // the blob carries numpy-RNG planes
+        return g2048_set_numpy_rng(e, reinterpret_cast<const uint64_t *>(body + e->slab_bytes), stream);
+    return g2048_set_numpy_rng(e, nullptr, stream);
 }
 
 } // extern "C"

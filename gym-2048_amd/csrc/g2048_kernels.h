@@ -23,7 +23,8 @@ struct DeviceState {
     uint4 *boards;         // [n]   16 x int8 exponents per board
     int32_t *score;        // [n]   episodic merge score (game2048_env.py:86)
     int32_t *last_score;   // [n]   final score of the board's last finished episode (write-only here)
-    WaveStats *wave_stats; // [ceil(n/64)]
+    WaveStats *wave_stats; // one per wavefront of the launch grid
+    uint64_t *rng;         // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
 };
 
 struct StepArgs {
@@ -60,6 +61,10 @@ hipError_t launch_move(uint4 *boards, uint32_t n, const void *actions, int actio
 hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8_t *isend_out, uint8_t *highest_out,
                         hipStream_t s);
 hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s);
+// the same three in numpy-RNG mode (a.st.rng != NULL)
+hipError_t launch_reset_numpy(const StepArgs &a, const uint8_t *mask, hipStream_t s);
+hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s);
+hipError_t launch_add_tile_numpy(const StepArgs &a, hipStream_t s);
 hipError_t launch_fill_actions(uint8_t *out, uint32_t n, uint32_t board_offset, uint32_t seed_lo, uint32_t seed_hi,
                                uint64_t t_first, uint32_t k_steps, hipStream_t s);
 hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dtype, hipStream_t s);

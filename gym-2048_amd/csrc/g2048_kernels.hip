@@ -13,6 +13,7 @@
 #include "g2048_kernels.h"
 
 #include "g2048_device.h"
+#include "g2048_pcg64.h"
 
 
 namespace g2048 {
@@ -172,6 +173,88 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
         p.st.score[i] = score;
     }
     flush_wave_stats(p, i_raw, p.st.wave_stats[i_raw >> 6], acc);
+}
+
+// ------------------------------------------------------------------------- numpy-RNG mode
+// Same step / reset / add_tile, drawing from each board's own PCG64 exactly as numpy would
+// (g2048_pcg64.h).  RNG state: five coalesced 8-byte planes.
+__device__ __forceinline__ Pcg64 load_rng(const uint64_t *planes, uint32_t n, uint32_t i)
+{
+    return Pcg64{planes[i], planes[n + i], planes[2ull * n + i], planes[3ull * n + i], planes[4ull * n + i]};
+}
+
+__device__ __forceinline__ void store_rng(uint64_t *planes, uint32_t n, uint32_t i, const Pcg64 &r)
+{
+    planes[i] = r.state_lo;
+    planes[n + i] = r.state_hi;
+    planes[4ull * n + i] = r.buf; // inc never changes
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
+{
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
+    const uint4 v = p.st.boards[i];
+    Board bd{{v.x, v.y, v.z, v.w}};
+    int32_t score = p.st.score[i];
+    Pcg64 rng = load_rng(p.st.rng, p.n, i);
+    const WaveStats old_stats = p.st.wave_stats[i_raw >> 6];
+    uint32_t action;
+    if constexpr (ACT == 0)
+        action = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi).w[3] >> 30;
+    else
+        action = load_action<ACT>(p.actions, i, 0u);
+
+    StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+
+    if (valid) {
+        p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+        p.st.score[i] = score;
+        store_rng(p.st.rng, p.n, i, rng);
+        if (p.reward)
+            p.reward[i] = r.reward;
+        if (p.terminated)
+            p.terminated[i] = r.terminated ? 1 : 0;
+        if (p.illegal)
+            p.illegal[i] = r.illegal ? 1 : 0;
+        if (p.highest)
+            p.highest[i] = static_cast<uint8_t>(highest(r.terminal));
+    }
+    r.terminated = r.terminated && valid;
+    WaveAcc acc;
+    record_episodes(p, i, r, acc);
+    flush_wave_stats(p, i_raw, old_stats, acc);
+}
+
+__global__ void __launch_bounds__(kBlock) reset_numpy_kernel(const StepArgs p, const uint8_t *mask)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n || (mask && mask[i] == 0))
+        return;
+    Pcg64 rng = load_rng(p.st.rng, p.n, i);
+    Board bd{{0u, 0u, 0u, 0u}};   // game2048_env.py:104
+    add_tile_numpy(bd, rng);      // :108
+    add_tile_numpy(bd, rng);      // :109
+    store_rng(p.st.rng, p.n, i, rng);
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    p.st.score[i] = 0;            // :105
+}
+
+__global__ void __launch_bounds__(kBlock) add_tile_numpy_kernel(const StepArgs p)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n)
+        return;
+    const uint4 v = p.st.boards[i];
+    Board bd{{v.x, v.y, v.z, v.w}};
+    if (count_empty(bd) == 0)
+        return;
+    Pcg64 rng = load_rng(p.st.rng, p.n, i);
+    add_tile_numpy(bd, rng);
+    store_rng(p.st.rng, p.n, i, rng);
+    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
 }
 
 // ---------------------------------------------------------------------------------- reset
@@ -407,6 +490,37 @@ hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s)
     if (a.n == 0)
         return hipSuccess;
     hipLaunchKernelGGL(add_tile_kernel, grid_for(a.n), dim3(kBlock), 0, s, a, slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset_numpy(const StepArgs &a, const uint8_t *mask, hipStream_t s)
+{
+    if (a.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(reset_numpy_kernel, grid_for(a.n), dim3(kBlock), 0, s, a, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s)
+{
+    if (a.n == 0)
+        return hipSuccess;
+    const dim3 g = grid_for(a.n), b(kBlock);
+    switch (action_dtype) {
+    case 0: hipLaunchKernelGGL(step_numpy_kernel<0>, g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL(step_numpy_kernel<1>, g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(step_numpy_kernel<2>, g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(step_numpy_kernel<3>, g, b, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_add_tile_numpy(const StepArgs &a, hipStream_t s)
+{
+    if (a.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(add_tile_numpy_kernel, grid_for(a.n), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

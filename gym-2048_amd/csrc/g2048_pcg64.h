@@ -1,0 +1,134 @@
+// g2048_pcg64.h -- numpy-compatible RNG mode: the reference's OWN randomness on the device.
+//
+// The reference draws from self.np_random (game2048_env.py:168,170), which gymnasium creates as
+// numpy.random.Generator(PCG64(SeedSequence(seed))).  In this mode every board carries the state of
+// its own PCG64 (seeded on the host by numpy itself, board i <- seed + i like SB3's make_vec_env) and
+// the kernels consume it exactly as numpy would:
+//   next64   : state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc (mod 2^128),
+//              out = rotr64(hi ^ lo, state >> 122)                 [numpy random/src/pcg64/pcg64.h]
+//   next32   : low half of a fresh next64, the high half is buffered for the following call
+//   random() : (next64 >> 11) * 2^-53; "< 0.9" <=> (next64 >> 11) < 8106479329266893 (0.9 * 2^53 exactly)
+//   shuffle  : for i = 15 .. 1: j = interval(i); swap(pos[i], pos[j])   [_generator.pyx, untyped path]
+//   interval : masked rejection on next32                        [distributions.c random_interval]
+// With it, board i plays bit-for-bit the game the unmodified reference env plays after
+// reset(seed = s + i) (tests/golden/traj_numpy_*.npz).  It costs ~5x the spawn-stream mode (about
+// ten 128-bit LCG steps per spawn, divergent rejection loops, 40 B/board of RNG state per step) and
+// exists for fidelity, not for the benchmark.
+#pragma once
+
+#include "g2048_device.h"
+
+#if defined(G2048_HOST_CHECK)
+static inline uint64_t g2048_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+#else
+G2048_DEV uint64_t g2048_mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
+#endif
+
+namespace g2048 {
+
+struct Pcg64 {
+    uint64_t state_lo, state_hi, inc_lo, inc_hi;
+    uint64_t buf; // bits 0..31 buffered high half ("uinteger"), bit 32 = has_uint32
+};
+
+constexpr uint64_t kPcgMultHi = 0x2360ED051FC65DA4ull, kPcgMultLo = 0x4385DF649FCCF645ull;
+constexpr uint64_t kTwoThreshold53 = 8106479329266893ull; // 0.9 * 2^53 (0.9 as IEEE double)
+
+G2048_DEV uint64_t pcg64_next64(Pcg64 &r)
+{
+    // (state_hi:state_lo) * (MultHi:MultLo) + (inc_hi:inc_lo)  mod 2^128
+    const uint64_t lo = r.state_lo * kPcgMultLo;
+    uint64_t hi = g2048_mulhi64(r.state_lo, kPcgMultLo) + r.state_lo * kPcgMultHi + r.state_hi * kPcgMultLo;
+    const uint64_t new_lo = lo + r.inc_lo;
+    hi += r.inc_hi + (new_lo < lo ? 1ull : 0ull);
+    r.state_lo = new_lo;
+    r.state_hi = hi;
+    const uint64_t x = hi ^ new_lo;
+    const uint32_t rot = (uint32_t)(hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+G2048_DEV uint32_t pcg64_next32(Pcg64 &r)
+{
+    if (r.buf >> 32) {
+        const uint32_t v = (uint32_t)r.buf;
+        r.buf = 0;
+        return v;
+    }
+    const uint64_t next = pcg64_next64(r);
+    r.buf = (next >> 32) | (1ull << 32);
+    return (uint32_t)next;
+}
+
+// random_interval(max) for 1 <= max <= 15.
+G2048_DEV uint32_t pcg64_interval(Pcg64 &r, uint32_t max)
+{
+    const uint32_t mask = max >= 8u ? 15u : (max >= 4u ? 7u : (max >= 2u ? 3u : 1u));
+    uint32_t v;
+    do {
+        v = pcg64_next32(r) & mask;
+    } while (v > max);
+    return v;
+}
+
+// 16-bit mask of the empty cells, bit p = cell p (row-major).
+G2048_DEV uint32_t empty_mask16(const Board &bd)
+{
+    // z80 has bit 7 of every empty byte; (z * 0x00204081) >> 28 gathers bits 7,15,23,31 into a nibble
+    return ((z80(bd.r[0]) * 0x00204081u) >> 28) | (((z80(bd.r[1]) * 0x00204081u) >> 28) << 4) |
+           (((z80(bd.r[2]) * 0x00204081u) >> 28) << 8) | (((z80(bd.r[3]) * 0x00204081u) >> 28) << 12);
+}
+
+// game2048_env.py:166-176 with numpy's draws.  Precondition: at least one empty cell.
+G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
+{
+    const uint32_t exp = ((pcg64_next64(r) >> 11) < kTwoThreshold53) ? 1u : 2u; // :168
+    uint64_t pos = 0xFEDCBA9876543210ull;                                       // :169 nibble i = position i
+    for (uint32_t i = 15; i >= 1; --i) {                                        // :170 Generator.shuffle
+        const uint32_t j = pcg64_interval(r, i);
+        const uint64_t d = ((pos >> (4u * i)) ^ (pos >> (4u * j))) & 15ull;     // swap nibbles i and j
+        pos ^= (d << (4u * i)) | (d << (4u * j));
+    }
+    const uint32_t empty = empty_mask16(bd);
+    uint32_t p = 0;
+    for (uint32_t k = 0; k < 16; ++k) {                                         // :171-175 first empty
+        p = (uint32_t)(pos >> (4u * k)) & 15u;
+        if ((empty >> p) & 1u)
+            break;
+    }
+    const uint32_t tile = exp << (8u * (p & 3u));
+    const uint32_t q = p >> 2;
+    bd.r[0] |= q == 0u ? tile : 0u;
+    bd.r[1] |= q == 1u ? tile : 0u;
+    bd.r[2] |= q == 2u ? tile : 0u;
+    bd.r[3] |= q == 3u ? tile : 0u;
+}
+
+// game2048_env.py:76-100 (+ the caller's `if terminated: env.reset()`, :102-111) in numpy-RNG mode.
+G2048_DEV StepResult step_env_numpy(Board &bd, int32_t &score, uint32_t action, Pcg64 &rng, float illegal_reward,
+                                    uint32_t max_exp, bool auto_reset)
+{
+    StepResult r;
+    uint32_t gain;
+    const bool legal = move(bd, action, gain);            // :85
+    bool end = false;
+    if (legal) {
+        add_tile_numpy(bd, rng);                          // :88
+        end = is_end(bd, max_exp);                        // :89
+    }
+    r.illegal = !legal;                                   // :91-95
+    r.terminated = legal ? end : true;
+    r.reward = legal ? (float)gain : illegal_reward;
+    score += (int32_t)gain;                               // :86
+    r.terminal = bd;
+    r.terminal_score = score;
+    if (r.terminated && auto_reset) {
+        bd = Board{{0u, 0u, 0u, 0u}};                     // :104
+        score = 0;                                        // :105
+        add_tile_numpy(bd, rng);                          // :108
+        add_tile_numpy(bd, rng);                          // :109
+    }
+    return r;
+}
+
+} // namespace g2048

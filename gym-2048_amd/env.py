@@ -66,7 +66,7 @@ class Game2048Env:
     metadata = {"render_modes": ["ansi", "human", "rgb_array"], "render_fps": 4}  # game2048_env.py:35
     _all_positions = [(r, c) for r in range(4) for c in range(4)]                  # game2048_env.py:36
 
-    def __init__(self, render_mode=None, *, device: int = 0, engine=None):
+    def __init__(self, render_mode=None, *, device: int = 0, engine=None, rng: str = "philox"):
         # game2048_env.py:38-58
         self.size = 4
         self.w = self.size
@@ -76,7 +76,7 @@ class Game2048Env:
         self.action_space, self.observation_space = make_spaces()
         if engine is None:
             from .batched import Batched2048
-            engine = Batched2048(1, device=device, seed=int.from_bytes(os.urandom(8), "little"))
+            engine = Batched2048(1, device=device, seed=int.from_bytes(os.urandom(7), "little"), rng=rng)
         self._eng = engine
         self._slot = 0          # next spawn slot of the current transaction
         self.set_illegal_move_reward(0.0)

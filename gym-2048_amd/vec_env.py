@@ -28,10 +28,11 @@ class Vec2048:
     metadata = {"render_modes": ["ansi", "human", "rgb_array"], "render_fps": 4}
 
     def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
-                 illegal_move_reward: float = 0.0, max_tile=None, obs_dtype=np.int64, engine=None):
+                 illegal_move_reward: float = 0.0, max_tile=None, obs_dtype=np.int64, engine=None,
+                 rng: str = "philox"):
         if engine is None:
             from .batched import Batched2048
-            engine = Batched2048(n_envs, device=device, seed=seed, board_offset=board_offset)
+            engine = Batched2048(n_envs, device=device, seed=seed, board_offset=board_offset, rng=rng)
         self.engine = engine
         self.num_envs = int(n_envs)
         self.action_space, self.observation_space = make_spaces()

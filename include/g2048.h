@@ -163,6 +163,17 @@ void *g2048_last_score_ptr(const g2048_engine *e);
 /* Reduce the episode bookkeeping on the device and copy the result to *out (synchronises `stream`). */
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
 
+/* numpy-compatible RNG mode: every board draws from its OWN numpy PCG64 exactly as the reference does
+ * through gymnasium's np_random (game2048_env.py:103,168,170: random() < 0.9, then Generator.shuffle of
+ * the 16 positions, first empty one).  `planes` = uint64[5][n] in host or device memory: state_lo,
+ * state_hi, inc_lo, inc_hi of numpy's PCG64(SeedSequence(seed_i)).state and buf = uinteger |
+ * has_uint32 << 32 (the host computes them with numpy; SB3 seeds env i with seed + i).  After this call
+ * reset/step/rollout/add_tile consume those generators; board i then plays bit-for-bit the game of the
+ * unmodified reference env after reset(seed = seed_i).  planes == NULL returns to the spawn stream.
+ * About 5x slower than the spawn stream; g2048_rollout_random is not available in this mode. */
+int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream);
+int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream);
+
 /* Checkpoint / resume of the complete engine state (boards, scores, episode bookkeeping, seed,
  * clock, configuration) as one host blob of g2048_state_bytes() bytes.  The reference checkpoints
  * only models; its env state hooks are get_board/set_board (game2048_env.py:282-288). */

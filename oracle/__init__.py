@@ -61,6 +61,17 @@ def load():
     lib.g2048o_reset_batch.argtypes = [C.POINTER(_Batch), u64, u64, u64, u64, u32, C.c_int]
     lib.g2048o_step_batch.argtypes = [C.POINTER(_Batch), u64, u64, u64, u64, C.c_float, C.c_int, C.c_int, C.c_int]
     lib.g2048o_onehot_batch.argtypes = [C.c_void_p, u64, C.c_void_p]
+    lib.g2048o_pcg64_next64.argtypes = [C.c_void_p]
+    lib.g2048o_pcg64_next64.restype = u64
+    lib.g2048o_pcg64_next32.argtypes = [C.c_void_p]
+    lib.g2048o_pcg64_next32.restype = u32
+    lib.g2048o_pcg64_interval.argtypes = [C.c_void_p, u32]
+    lib.g2048o_pcg64_interval.restype = u32
+    lib.g2048o_add_tile_numpy.argtypes = [i64p, C.c_void_p]
+    lib.g2048o_add_tile_numpy.restype = C.c_int
+    lib.g2048o_reset_batch_numpy.argtypes = [C.POINTER(_Batch), C.c_void_p, u64, u64, C.c_int]
+    lib.g2048o_step_batch_numpy.argtypes = [C.POINTER(_Batch), C.c_void_p, u64, u64, u64, u64, C.c_float, C.c_int,
+                                            C.c_int, C.c_int]
     _lib = lib
     return lib
 
@@ -121,7 +132,40 @@ class OracleBatch:
         self.lib.g2048o_step_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset,
                                    self.illegal_move_reward, self.max_exp, int(auto_reset), self.threads)
 
+    # -- numpy-compatible RNG mode: rng[i] = (state_lo, state_hi, inc_lo, inc_hi, buf) of board i
+    def seed_numpy(self, seed: int):
+        """Board i gets numpy's PCG64(SeedSequence(seed + board_offset + i)) -- what gymnasium gives
+        env i of a vector env seeded with ``seed`` (SB3 seeds env i with seed + i)."""
+        self.rng = pcg64_states_from_seeds(seed + self.board_offset + np.arange(self.n))
+        self.seed, self.t, self.fresh = seed, 0, True
+
+    def reset_numpy(self):
+        b = self._batch()
+        self.fresh = False
+        self.lib.g2048o_reset_batch_numpy(C.byref(b), self.rng.ctypes.data, self.n, self.t, self.threads)
+
+    def step_numpy(self, actions=None, auto_reset: bool = True):
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        self.t += 1
+        b = self._batch(actions)
+        self.lib.g2048o_step_batch_numpy(C.byref(b), self.rng.ctypes.data, self.n, self.seed, self.t,
+                                         self.board_offset, self.illegal_move_reward, self.max_exp,
+                                         int(auto_reset), self.threads)
+
     def onehot(self):
         out = np.zeros((self.n, 16, 4, 4), np.uint8)
         self.lib.g2048o_onehot_batch(_ptr(self.boards), self.n, _ptr(out))
         return out
+
+
+def pcg64_states_from_seeds(seeds) -> np.ndarray:
+    """uint64 [n, 5] = (state_lo, state_hi, inc_lo, inc_hi, buf) of numpy's PCG64(SeedSequence(seed)),
+    the generator gymnasium builds for ``reset(seed=seed)``.  The SeedSequence hashing is numpy's own."""
+    m64 = (1 << 64) - 1
+    out = np.zeros((len(seeds), 5), np.uint64)
+    for i, s in enumerate(seeds):
+        st = np.random.PCG64(np.random.SeedSequence(int(s))).state
+        state, inc = st["state"]["state"], st["state"]["inc"]
+        out[i] = (state & m64, state >> 64, inc & m64, inc >> 64, st["uinteger"] | (st["has_uint32"] << 32))
+    return out

@@ -338,6 +338,137 @@ void g2048o_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t,
     }
 }
 
+/* ----------------------------------------------------------------- numpy-compatible RNG mode */
+
+typedef unsigned __int128 u128;
+
+uint64_t g2048o_pcg64_next64(g2048o_pcg64 *r)
+{
+    const u128 mult = ((u128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+    u128 state = ((u128)r->state_hi << 64) | r->state_lo;
+    const u128 inc = ((u128)r->inc_hi << 64) | r->inc_lo;
+    state = state * mult + inc;                       /* pcg_setseq_128_step_r */
+    r->state_lo = (uint64_t)state;
+    r->state_hi = (uint64_t)(state >> 64);
+    const uint64_t x = r->state_hi ^ r->state_lo;     /* pcg_output_xsl_rr_128_64 */
+    const unsigned rot = (unsigned)(r->state_hi >> 58);
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+
+uint32_t g2048o_pcg64_next32(g2048o_pcg64 *r)
+{
+    if (r->buf >> 32) {                               /* has_uint32 */
+        const uint32_t v = (uint32_t)r->buf;
+        r->buf = 0;
+        return v;
+    }
+    const uint64_t next = g2048o_pcg64_next64(r);
+    r->buf = (next >> 32) | (1ull << 32);
+    return (uint32_t)next;
+}
+
+uint32_t g2048o_pcg64_interval(g2048o_pcg64 *r, uint32_t max)
+{
+    uint32_t mask = max, value;
+    if (max == 0)
+        return 0;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    do {
+        value = g2048o_pcg64_next32(r) & mask;
+    } while (value > max);
+    return value;
+}
+
+/* game2048_env.py:166-176 */
+int g2048o_add_tile_numpy(int64_t M[16], g2048o_pcg64 *r)
+{
+    /* :168 random() < 0.9 in double, exactly as Python evaluates it */
+    const double u = (double)(g2048o_pcg64_next64(r) >> 11) * (1.0 / 9007199254740992.0);
+    const int64_t val = u < 0.9 ? 2 : 4;
+    int positions[16];
+    for (int i = 0; i < 16; ++i)                       /* :169 row-major (r, c) -> r*4+c */
+        positions[i] = i;
+    for (int i = 15; i >= 1; --i) {                    /* :170 Generator.shuffle(list) */
+        const int j = (int)g2048o_pcg64_interval(r, (uint32_t)i);
+        const int tmp = positions[i];
+        positions[i] = positions[j];
+        positions[j] = tmp;
+    }
+    for (int i = 0; i < 16; ++i)                       /* :171-175 */
+        if (M[positions[i]] == 0) {
+            M[positions[i]] = val;
+            return positions[i];
+        }
+    return -1;                                         /* :176 */
+}
+
+void g2048o_reset_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t t, int threads)
+{
+    set_threads(threads);
+#pragma omp parallel for schedule(static) if (threads != 1)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        int64_t M[16] = { 0 };                          /* :104 */
+        g2048o_add_tile_numpy(M, &rng[i]);              /* :108 */
+        g2048o_add_tile_numpy(M, &rng[i]);              /* :109 */
+        g2048o_values_to_exp(M, s->boards + 16 * i);
+        if (s->score) s->score[i] = 0;
+        if (s->ep_start) s->ep_start[i] = (uint32_t)t;
+    }
+}
+
+void g2048o_step_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t seed, uint64_t t,
+                             uint64_t board_offset, float illegal_move_reward, int max_exp, int auto_reset,
+                             int threads)
+{
+    const int64_t max_tile = max_exp ? ((int64_t)1 << max_exp) : 0;
+    set_threads(threads);
+#pragma omp parallel for schedule(static) if (threads != 1)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        int64_t M[16], ms = 0, hi;
+        int action, terminated, illegal;
+        float reward;
+        int32_t score = s->score ? s->score[i] : 0;
+        g2048o_exp_to_values(s->boards + 16 * i, M);
+        action = (s->actions ? s->actions[i]
+                             : g2048o_random_action(seed, t, (uint32_t)(board_offset + (uint64_t)i))) & 3;
+        if (g2048o_move(M, action, 0, &ms)) {           /* :85 */
+            score += (int32_t)ms;                       /* :86 */
+            g2048o_add_tile_numpy(M, &rng[i]);          /* :88 */
+            terminated = g2048o_isend(M, max_tile);     /* :89 */
+            reward = (float)ms;
+            illegal = 0;
+        } else {                                        /* :91-95 */
+            illegal = 1;
+            terminated = 1;
+            reward = illegal_move_reward;
+        }
+        hi = g2048o_highest(M);
+        if (s->reward) s->reward[i] = reward;
+        if (s->terminated) s->terminated[i] = (uint8_t)terminated;
+        if (s->illegal) s->illegal[i] = (uint8_t)illegal;
+        if (s->highest) {
+            uint8_t e = 0;
+            while (hi > 1) { hi >>= 1; ++e; }
+            s->highest[i] = e;
+        }
+        if (terminated) {
+            if (s->terminal_boards) g2048o_values_to_exp(M, s->terminal_boards + 16 * i);
+            if (s->last_score) s->last_score[i] = score;
+            if (s->last_len && s->ep_start) s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
+            if (s->ep_count) s->ep_count[i] += 1;
+            if (auto_reset) {                           /* `if terminated: env.reset()` (:102-111) */
+                memset(M, 0, sizeof M);
+                score = 0;
+                g2048o_add_tile_numpy(M, &rng[i]);
+                g2048o_add_tile_numpy(M, &rng[i]);
+                if (s->ep_start) s->ep_start[i] = (uint32_t)t;
+            }
+        }
+        g2048o_values_to_exp(M, s->boards + 16 * i);
+        if (s->score) s->score[i] = score;
+    }
+}
+
 void g2048o_onehot_batch(const uint8_t *boards, uint64_t n, uint8_t *out)
 {
     for (uint64_t i = 0; i < n; ++i) {

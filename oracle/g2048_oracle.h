@@ -124,6 +124,38 @@ void g2048o_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t,
                        uint64_t board_offset, float illegal_move_reward, int max_exp,
                        int auto_reset, int threads);
 
+/* ------------------------------------------------------------------ numpy-compatible RNG mode
+ * The reference's own RNG: gymnasium's np_random = numpy Generator(PCG64(SeedSequence(seed)))
+ * (game2048_env.py:103,168,170).  Third-party algorithms (numpy random/src/pcg64/pcg64.h,
+ * src/distributions/distributions.c: random_interval, _generator.pyx: shuffle), restated:
+ *   next64:  state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc (mod 2^128);
+ *            out = rotr64(hi ^ lo, state >> 122)
+ *   next32:  low half of a fresh next64 first, the high half is buffered
+ *   random(): (next64 >> 11) * 2^-53
+ *   shuffle(list of n): for i = n-1 .. 1: j = interval(i); swap(x[i], x[j])
+ *   interval(max): mask = 2^ceil(log2(max+1)) - 1; do v = next32 & mask while v > max
+ * Seeding (SeedSequence hashing) is done by numpy itself on the host; this mode starts from the
+ * PCG64 state numpy reports.  Pinned against numpy by tests/test_numpy_rng.py and against the
+ * unmodified reference by tests/golden/traj_numpy_*.npz. */
+typedef struct {
+    uint64_t state_lo, state_hi, inc_lo, inc_hi;
+    uint64_t buf; /* bits 0..31 = buffered high half ("uinteger"), bit 32 = has_uint32 */
+} g2048o_pcg64;
+
+uint64_t g2048o_pcg64_next64(g2048o_pcg64 *r);
+uint32_t g2048o_pcg64_next32(g2048o_pcg64 *r);
+uint32_t g2048o_pcg64_interval(g2048o_pcg64 *r, uint32_t max);
+/* game2048_env.py:166-176 with numpy's draws: random() < 0.9, shuffle of the 16 positions, first
+ * empty one.  Returns the flat index of the new tile or -1 (board full). */
+int g2048o_add_tile_numpy(int64_t M[16], g2048o_pcg64 *r);
+
+/* Batch drivers as g2048o_reset_batch / g2048o_step_batch, drawing from rng[i] (one PCG64 per
+ * board).  seed/t/board_offset only feed the synthetic action stream when s->actions is NULL. */
+void g2048o_reset_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t t, int threads);
+void g2048o_step_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t seed, uint64_t t,
+                             uint64_t board_offset, float illegal_move_reward, int max_exp, int auto_reset,
+                             int threads);
+
 /* (n,16) exponents -> (n,16,4,4) one-hot uint8 (game2048_env.py:17-32). */
 void g2048o_onehot_batch(const uint8_t *boards, uint64_t n, uint8_t *out);
 

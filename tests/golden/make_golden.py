@@ -262,6 +262,42 @@ def gen_trajectories(ref, name, seed, n_boards, n_steps, policy, board_offset=0,
     return out
 
 
+def gen_numpy_trajectories(ref, seed, n_boards, n_steps, illegal_move_reward=None):
+    """The UNMODIFIED reference with ITS OWN RNG: env i is seeded ``reset(seed=seed + i)`` (what SB3's
+    make_vec_env does), i.e. np_random = Generator(PCG64(SeedSequence(seed + i))) exactly as gymnasium
+    creates it.  Actions are inputs: the synthetic policy stream random_action(seed, t, i)."""
+    shape = (n_boards, n_steps)
+    out = dict(actions=np.zeros(shape, np.uint8), reward=np.zeros(shape, np.float32),
+               terminated=np.zeros(shape, np.uint8), illegal=np.zeros(shape, np.uint8),
+               highest=np.zeros(shape, np.uint8), score=np.zeros(shape, np.int32),
+               boards=np.zeros(shape + (16,), np.uint8), terminal_boards=np.zeros(shape + (16,), np.uint8),
+               terminal_score=np.zeros(shape, np.int32), initial_boards=np.zeros((n_boards, 16), np.uint8))
+    for b in range(n_boards):
+        env = ref.Game2048Env()
+        if illegal_move_reward is not None:
+            env.set_illegal_move_reward(illegal_move_reward)
+        env.reset(seed=seed + b)
+        out["initial_boards"][b] = values_to_exp(env.get_board()).reshape(16)
+        for s in range(n_steps):
+            a = random_action(seed, s + 1, b)
+            obs, reward, terminated, truncated, info = env.step(a)
+            out["actions"][b, s] = a
+            out["reward"][b, s] = reward
+            out["terminated"][b, s] = terminated
+            out["illegal"][b, s] = info["illegal_move"]
+            out["highest"][b, s] = values_to_exp(info["highest"])
+            out["terminal_boards"][b, s] = values_to_exp(env.get_board()).reshape(16)
+            out["terminal_score"][b, s] = env.score
+            if terminated:
+                env.reset()
+            out["boards"][b, s] = values_to_exp(env.get_board()).reshape(16)
+            out["score"][b, s] = env.score
+    out["meta"] = np.array([seed, 0, n_boards, n_steps, 0, 1], np.int64)
+    out["illegal_move_reward"] = np.array([0.0 if illegal_move_reward is None else illegal_move_reward], np.float32)
+    out["numpy_version"] = np.array(np.__version__)
+    return out
+
+
 def gen_reference_test_kats(ref):
     """Re-capture, by calling the reference, the values its own unit tests pin
     (test_game2048_env.py:13-34 shift rows, :40-98 move board, :113-151 isend, :165-217 step)."""
@@ -425,6 +461,7 @@ def time_reference(ref, report):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--validate-steps", type=int, default=1_000_000)
+    ap.add_argument("--only-numpy", action="store_true", help="only (re)generate the numpy-RNG trajectories")
     args = ap.parse_args()
     ref = import_reference()
     rng = np.random.default_rng(20480)
@@ -436,6 +473,11 @@ def main():
         h = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
         report.append(f"{name}: {os.path.getsize(path)} bytes sha256[:16]={h}")
 
+    save("traj_numpy_seed42.npz", gen_numpy_trajectories(ref, 42, 48, 256))
+    save("traj_numpy_seed7_irw.npz", gen_numpy_trajectories(ref, 7, 16, 512, illegal_move_reward=-1.0))
+    if args.only_numpy:
+        print("\n".join(report))
+        return
     save("shift_exhaustive.npz", gen_shift_table(ref))
     save("move_table.npz", gen_move_table(ref, rng))
     save("isend_table.npz", gen_isend_table(ref, rng))

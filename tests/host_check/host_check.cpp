@@ -4,6 +4,7 @@
 // step_kernel / reset_kernel (g2048_kernels.hip) one board at a time.  Not part of the product.
 #define G2048_HOST_CHECK 1
 #include "../../gym-2048_amd/csrc/g2048_device.h"
+#include "../../gym-2048_amd/csrc/g2048_pcg64.h"
 #include "../../oracle/g2048_oracle.h"
 
 #include <cstring>
@@ -98,6 +99,63 @@ void hostcheck_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t
                                       (uint32_t)seed, (uint32_t)(seed >> 32));
         const uint32_t action = s->actions ? (s->actions[i] & 3u) : (w.w[3] >> 30);
         const StepResult r = step_env(bd, score, action, w, illegal_move_reward, (uint32_t)max_exp, auto_reset != 0);
+        if (s->reward) s->reward[i] = r.reward;
+        if (s->terminated) s->terminated[i] = r.terminated;
+        if (s->illegal) s->illegal[i] = r.illegal;
+        if (s->highest) s->highest[i] = (uint8_t)highest(r.terminal);
+        if (r.terminated) {
+            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, r.terminal);
+            s->last_score[i] = r.terminal_score;
+            s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
+            s->ep_count[i] += 1;
+            if (auto_reset) s->ep_start[i] = (uint32_t)t;
+        }
+        store_board(s->boards + 16 * i, bd);
+        s->score[i] = score;
+    }
+}
+
+// ---- numpy-compatible RNG mode (g2048_pcg64.h); rng = [n][5] uint64 as in the oracle
+static Pcg64 load_rng(const g2048o_pcg64 *r) { return Pcg64{r->state_lo, r->state_hi, r->inc_lo, r->inc_hi, r->buf}; }
+static void store_rng(g2048o_pcg64 *r, const Pcg64 &p)
+{
+    r->state_lo = p.state_lo; r->state_hi = p.state_hi; r->inc_lo = p.inc_lo; r->inc_hi = p.inc_hi; r->buf = p.buf;
+}
+
+uint64_t hostcheck_pcg64_next64(g2048o_pcg64 *r) { Pcg64 p = load_rng(r); const uint64_t v = pcg64_next64(p); store_rng(r, p); return v; }
+uint32_t hostcheck_pcg64_next32(g2048o_pcg64 *r) { Pcg64 p = load_rng(r); const uint32_t v = pcg64_next32(p); store_rng(r, p); return v; }
+uint32_t hostcheck_pcg64_interval(g2048o_pcg64 *r, uint32_t mx) { Pcg64 p = load_rng(r); const uint32_t v = pcg64_interval(p, mx); store_rng(r, p); return v; }
+uint32_t hostcheck_empty_mask16(const uint8_t b[16]) { return empty_mask16(load_board(b)); }
+
+void hostcheck_reset_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t t, int)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        Pcg64 p = load_rng(&rng[i]);
+        Board bd{{0, 0, 0, 0}};
+        add_tile_numpy(bd, p);
+        add_tile_numpy(bd, p);
+        store_rng(&rng[i], p);
+        store_board(s->boards + 16 * i, bd);
+        s->score[i] = 0;
+        s->ep_start[i] = (uint32_t)t;
+    }
+}
+
+void hostcheck_step_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t seed, uint64_t t,
+                                uint64_t board_offset, float illegal_move_reward, int max_exp, int auto_reset, int)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        Board bd = load_board(s->boards + 16 * i);
+        int32_t score = s->score[i];
+        Pcg64 p = load_rng(&rng[i]);
+        uint32_t action;
+        if (s->actions)
+            action = s->actions[i] & 3u;
+        else
+            action = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(board_offset + i), 0u, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32)).w[3] >> 30;
+        const StepResult r = step_env_numpy(bd, score, action, p, illegal_move_reward, (uint32_t)max_exp, auto_reset != 0);
+        store_rng(&rng[i], p);
         if (s->reward) s->reward[i] = r.reward;
         if (s->terminated) s->terminated[i] = r.terminated;
         if (s->illegal) s->illegal[i] = r.illegal;

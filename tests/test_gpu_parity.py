@@ -338,3 +338,81 @@ def test_vec_env_adapter_matches_oracle_backed_adapter(torch_cuda):
                 assert x["highest"] == y["highest"] and x["illegal_move"] == y["illegal_move"]
                 assert np.array_equal(x["terminal_observation"], y["terminal_observation"])
     assert real.render().shape == (280, 280, 3)
+
+
+# ---------------------------------------------------------------- numpy-compatible RNG mode
+
+@pytest.mark.parametrize("name", ["traj_numpy_seed42", "traj_numpy_seed7_irw"])
+def test_numpy_rng_mode_replays_the_reference_with_its_own_rng(torch_cuda, name):
+    """rng='numpy': board i == the UNMODIFIED reference env after reset(seed = s + i), drawing from
+    numpy's PCG64 exactly as gymnasium's np_random does (golden: tests/golden/traj_numpy_*.npz)."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    d = load_golden(name)
+    seed, _, n, steps, _, _ = (int(x) for x in d["meta"])
+    eng = Batched2048(n, seed=seed, rng="numpy", illegal_move_reward=float(d["illegal_move_reward"][0]))
+    eng.reset()
+    assert np.array_equal(eng.get_boards().reshape(n, 16), d["initial_boards"])
+    for s in range(steps):
+        eng.step(torch.as_tensor(d["actions"][:, s]))
+        assert np.array_equal(eng.get_boards().reshape(n, 16), d["boards"][:, s]), s
+        assert np.array_equal(eng.reward.cpu().numpy(), d["reward"][:, s])
+        assert np.array_equal(eng.terminated.cpu().numpy(), d["terminated"][:, s])
+        assert np.array_equal(eng.illegal.cpu().numpy(), d["illegal"][:, s])
+        assert np.array_equal(eng.highest.cpu().numpy(), d["highest"][:, s])
+        assert np.array_equal(eng.get_scores(), d["score"][:, s])
+
+
+def test_numpy_rng_mode_vs_oracle_and_generator_state(torch_cuda):
+    """4 096 boards x 48 steps against the C oracle's numpy mode, RNG states included; the final device
+    RNG state loaded into numpy Generators continues like the oracle's."""
+    from gym2048_amd.batched import Batched2048
+    from gym2048_amd.seeding import planes_to_generators
+    from oracle import OracleBatch
+    n, seed = 4096, 123
+    eng = Batched2048(n, seed=seed, rng="numpy")
+    ob = OracleBatch(n, seed, threads=0)
+    ob.seed_numpy(seed)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)
+    eng.reset()
+    ob.reset_numpy()
+    for s in range(48):
+        eng.step(None)
+        ob.step_numpy(None)
+        assert np.array_equal(eng.get_boards().reshape(n, 16), ob.boards), s
+        assert np.array_equal(eng.reward.cpu().numpy(), ob.reward)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)
+    assert np.array_equal(eng.get_scores(), ob.score)
+    gens = planes_to_generators(eng.get_numpy_rng()[:, :4])
+    from oracle.numpy_rng import NumpyPCG64
+    for g, col in zip(gens, ob.rng[:4]):
+        mine = NumpyPCG64(int(col[0]) | (int(col[1]) << 64), int(col[2]) | (int(col[3]) << 64),
+                          int(col[4]) >> 32, int(col[4]) & 0xFFFFFFFF)
+        assert g.random() == mine.random()
+    # checkpoint / resume carries the generators
+    state = eng.state_dict()
+    eng.step(None)
+    ref = eng.get_boards()
+    other = Batched2048(n, seed=1)
+    other.load_state_dict(state)
+    other.step(None)
+    assert np.array_equal(other.get_boards(), ref) and other.rng_mode == "numpy"
+    with pytest.raises(Exception):
+        eng.rollout_random(4)
+
+
+def test_single_env_numpy_mode_is_the_reference_env(torch_cuda):
+    """Game2048Env(rng='numpy').reset(seed=42) gives the reference's own first board (SURVEY 8c:
+    [[0,0,0,0],[0,0,2,0],[0,0,0,0],[0,2,0,0]] with numpy 2.x) and then its trajectory."""
+    from gym2048_amd import Game2048Env
+    d = load_golden("traj_numpy_seed42")
+    env = Game2048Env(rng="numpy")
+    env.reset(seed=42)
+    assert env.get_board().tolist() == [[0, 0, 0, 0], [0, 0, 2, 0], [0, 0, 0, 0], [0, 2, 0, 0]]
+    vals = lambda e: np.where(e > 0, 1 << e.astype(np.int64), 0).reshape(4, 4)  # noqa: E731
+    for s in range(96):
+        _, reward, term, _, info = env.step(int(d["actions"][0, s]))
+        assert reward == d["reward"][0, s] and term == bool(d["terminated"][0, s])
+        if term:
+            env.reset()
+        assert np.array_equal(env.get_board(), vals(d["boards"][0, s]))
