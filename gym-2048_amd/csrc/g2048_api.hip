@@ -111,7 +111,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 3; }
+int g2048_abi_version(void) { return 4; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -471,6 +471,19 @@ int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream)
     if (!e || !e->st.rng)
         return fail(G2048_ERR_INVALID, "engine is not in numpy-RNG mode");
     return copy_out(e, planes, e->st.rng, e->n * 40, stream);
+}
+
+int g2048_augment(const uint8_t *boards, const uint8_t *next_boards, const uint8_t *actions, uint64_t n,
+                  uint8_t *boards_out, uint8_t *next_out, uint8_t *actions_out, void *stream)
+{
+    if (!boards || !actions || !boards_out || !actions_out || (next_boards && !next_out))
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    if (n > 0x1fffffffull)
+        return fail(G2048_ERR_INVALID, "n too large");
+    G2048_HIP(g2048::launch_augment(reinterpret_cast<const uint4 *>(boards), reinterpret_cast<const uint4 *>(next_boards),
+                                    actions, static_cast<uint32_t>(n), reinterpret_cast<uint4 *>(boards_out),
+                                    reinterpret_cast<uint4 *>(next_out), actions_out, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
 }
 
 uint64_t g2048_state_bytes(const g2048_engine *e)

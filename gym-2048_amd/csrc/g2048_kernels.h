@@ -68,6 +68,8 @@ hipError_t launch_add_tile_numpy(const StepArgs &a, hipStream_t s);
 hipError_t launch_fill_actions(uint8_t *out, uint32_t n, uint32_t board_offset, uint32_t seed_lo, uint32_t seed_hi,
                                uint64_t t_first, uint32_t k_steps, hipStream_t s);
 hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dtype, hipStream_t s);
+hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const uint8_t *actions, uint32_t n,
+                          uint4 *boards_out, uint4 *next_out, uint8_t *actions_out, hipStream_t s);
 hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hipStream_t s);
 
 } // namespace g2048

@@ -389,6 +389,60 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------- augmentation
+// training_data.augment() (training_data.py:257-299) for board pairs on the device: the eight
+// symmetries [orig, hflip, rot1(orig), rot1(hflip), rot2(..), rot2(..), rot3(..), rot3(..)] with the
+// action remapped (hflip swaps 1 <-> 3, :262-267; a clockwise quarter turn adds 1 mod 4, :276).
+// One lane per (variant, transition); every access is a coalesced 16-byte load/store.
+__device__ __forceinline__ Board hflip_board(const Board &b) // np.flip(x, 2): reverse every row
+{
+    return Board{{__builtin_bswap32(b.r[0]), __builtin_bswap32(b.r[1]), __builtin_bswap32(b.r[2]), __builtin_bswap32(b.r[3])}};
+}
+
+__device__ __forceinline__ Board rotate_board(const Board &b, uint32_t k) // np.rot90(x, k, axes=(2, 1)): clockwise
+{
+    const Board t = transpose(b);
+    if (k == 1u) // out[r][c] = in[3-c][r]
+        return Board{{__builtin_bswap32(t.r[0]), __builtin_bswap32(t.r[1]), __builtin_bswap32(t.r[2]), __builtin_bswap32(t.r[3])}};
+    if (k == 2u) // out[r][c] = in[3-r][3-c]
+        return Board{{__builtin_bswap32(b.r[3]), __builtin_bswap32(b.r[2]), __builtin_bswap32(b.r[1]), __builtin_bswap32(b.r[0])}};
+    if (k == 3u) // out[r][c] = in[c][3-r]
+        return Board{{t.r[3], t.r[2], t.r[1], t.r[0]}};
+    return b;
+}
+
+__global__ void __launch_bounds__(kBlock) augment_kernel(const uint4 *__restrict__ boards, const uint4 *__restrict__ next_boards,
+                                                         const uint8_t *__restrict__ actions, uint32_t n,
+                                                         uint4 *__restrict__ boards_out, uint4 *__restrict__ next_out,
+                                                         uint8_t *__restrict__ actions_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t variant = blockIdx.y; // 0..7
+    if (i >= n)
+        return;
+    const uint32_t flip = variant & 1u, k = variant >> 1;
+    uint4 v = boards[i];
+    Board b{{v.x, v.y, v.z, v.w}};
+    uint32_t a = actions[i];
+    if (flip) {
+        b = hflip_board(b);
+        a = (a == 1u) ? 3u : (a == 3u ? 1u : a);
+    }
+    b = rotate_board(b, k);
+    a = (a + k) & 3u;
+    const size_t o = static_cast<size_t>(variant) * n + i;
+    boards_out[o] = make_uint4(b.r[0], b.r[1], b.r[2], b.r[3]);
+    actions_out[o] = static_cast<uint8_t>(a);
+    if (next_boards) {
+        v = next_boards[i];
+        Board nb{{v.x, v.y, v.z, v.w}};
+        if (flip)
+            nb = hflip_board(nb);
+        nb = rotate_board(nb, k);
+        next_out[o] = make_uint4(nb.r[0], nb.r[1], nb.r[2], nb.r[3]);
+    }
+}
+
 // ----------------------------------------------------------------------------------- stats
 // Reduce the per-wave accumulators (and the highest tile on any board) to one StatsOut.
 // Block-level tree in LDS first, then ONE set of atomics per block (a single hot word serialises at
@@ -570,6 +624,16 @@ hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dty
     }
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const uint8_t *actions, uint32_t n,
+                          uint4 *boards_out, uint4 *next_out, uint8_t *actions_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(augment_kernel, dim3(grid_for(n).x, 8), dim3(kBlock), 0, s, boards, next_boards, actions, n,
+                       boards_out, next_out, actions_out);
     return hipGetLastError();
 }
 

@@ -174,6 +174,14 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
 int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream);
 int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream);
 
+/* training_data.augment() (training_data.py:257-299) on the current device: n transitions
+ * (boards[n][16], optional next_boards[n][16], actions uint8[n]; device pointers, 16-byte aligned) ->
+ * the eight symmetries, 8n rows in the reference's order [orig, hflip, rot1(orig), rot1(hflip), rot2(..),
+ * rot2(..), rot3(..), rot3(..)], actions remapped (hflip swaps 1<->3; a clockwise quarter turn adds 1 mod 4).
+ * next_boards / next_out may both be NULL.  Needs no engine. */
+int g2048_augment(const uint8_t *boards, const uint8_t *next_boards, const uint8_t *actions, uint64_t n,
+                  uint8_t *boards_out, uint8_t *next_out, uint8_t *actions_out, void *stream);
+
 /* Checkpoint / resume of the complete engine state (boards, scores, episode bookkeeping, seed,
  * clock, configuration) as one host blob of g2048_state_bytes() bytes.  The reference checkpoints
  * only models; its env state hooks are get_board/set_board (game2048_env.py:282-288). */

@@ -298,6 +298,28 @@ def gen_numpy_trajectories(ref, seed, n_boards, n_steps, illegal_move_reward=Non
     return out
 
 
+def gen_training_data_fixtures(report):
+    """The reference's data format either side of the step path: training_data.export_csv text and
+    training_data.augment() arrays, produced by the reference's own class (training_data.py) from
+    32 rows of its fixture data/test_data.csv plus two synthetic episode ends."""
+    import training_data as td_mod  # /root/reference/training_data.py (pure numpy)
+    raw = np.loadtxt(os.path.join(REFERENCE, "data", "test_data.csv"), delimiter=",", skiprows=1)[:32]
+    td = td_mod.training_data()
+    for i, row in enumerate(raw):
+        td.add(row[:16].astype(int), int(row[16]), float(row[17]), row[18:34].astype(int), done=(i in (11, 31)))
+    for name, add_returns in (("transitions_ref.csv", False), ("transitions_ref_returns.csv", True)):
+        path = os.path.join(HERE, name)
+        td.export_csv(path, add_returns=add_returns)
+        report.append(f"{name}: {os.path.getsize(path)} bytes (written by the reference's training_data.export_csv)")
+    base = dict(x=td.get_x().copy(), action=td.get_y_digit().copy(), reward=td.get_reward().copy(),
+                next_x=td.get_next_x().copy(), done=td.get_done().copy(),
+                returns=td.get_discounted_return().copy())
+    td.augment()
+    base.update(aug_x=td.get_x(), aug_action=td.get_y_digit(), aug_next_x=td.get_next_x(),
+                aug_reward=td.get_reward(), aug_done=td.get_done())
+    return base
+
+
 def gen_reference_test_kats(ref):
     """Re-capture, by calling the reference, the values its own unit tests pin
     (test_game2048_env.py:13-34 shift rows, :40-98 move board, :113-151 isend, :165-217 step)."""
@@ -462,6 +484,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--validate-steps", type=int, default=1_000_000)
     ap.add_argument("--only-numpy", action="store_true", help="only (re)generate the numpy-RNG trajectories")
+    ap.add_argument("--only-data", action="store_true", help="only (re)generate the training_data fixtures")
     args = ap.parse_args()
     ref = import_reference()
     rng = np.random.default_rng(20480)
@@ -473,6 +496,11 @@ def main():
         h = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
         report.append(f"{name}: {os.path.getsize(path)} bytes sha256[:16]={h}")
 
+    if args.only_data:
+        save("training_data_fixture.npz", gen_training_data_fixtures(report))
+        print("\n".join(report))
+        return
+    save("training_data_fixture.npz", gen_training_data_fixtures(report))
     save("traj_numpy_seed42.npz", gen_numpy_trajectories(ref, 42, 48, 256))
     save("traj_numpy_seed7_irw.npz", gen_numpy_trajectories(ref, 7, 16, 512, illegal_move_reward=-1.0))
     if args.only_numpy:
