@@ -27,7 +27,7 @@ template <typename T> __device__ __forceinline__ T *at(T *base, uint32_t idx)
     return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<std::remove_const_t<T> *>(base)) + (uint64_t)(idx * (uint32_t)sizeof(T)));
 }
 
-enum { F_SCORE = 1, F_RECORD = 2, F_COMPUTE = 4, F_STORE = 8, F_PIPE = 16, F_IDX64 = 32, F_PRIO8 = 64, F_PRIO11 = 128, F_PRIOW = 256 };
+enum { F_SCORE = 1, F_RECORD = 2, F_COMPUTE = 4, F_STORE = 8, F_PIPE = 16, F_IDX64 = 32, F_PRIO8 = 64, F_PRIO11 = 128, F_PRIOW = 256, F_TWO = 512, F_TWO_LATE = 1024 };
 
 template <int FLAGS>
 __device__ __forceinline__ void do_board(const Args &p, uint32_t i, uint4 v, int32_t score_in, uint32_t action)
@@ -79,6 +79,29 @@ __global__ void __launch_bounds__(256) kern(const Args p)
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
         }
+    }
+    if (FLAGS & (F_TWO | F_TWO_LATE)) {
+        // straight-line two boards per lane: board i and board i + n/2 (grid covers n/2 lanes)
+        const uint32_t i2 = i + p.n / 2;
+        if (i >= p.n / 2) return;
+        uint4 va, vb; int32_t sa, sb; uint32_t aa, ab;
+        if (FLAGS & F_IDX64) {
+            va = p.boards[i]; sa = p.score[i]; aa = p.actions[i];
+            vb = p.boards[i2]; sb = p.score[i2]; ab = p.actions[i2];
+            do_board<FLAGS>(p, i, va, sa, aa);
+            do_board<FLAGS>(p, i2, vb, sb, ab);
+            return;
+        }
+        va = *at(p.boards, i); sa = *at(p.score, i); aa = *at(p.actions, i);
+        if (FLAGS & F_TWO) { vb = *at(p.boards, i2); sb = *at(p.score, i2); ab = *at(p.actions, i2); }
+        if (FLAGS & F_TWO_LATE) {
+            // request B only once A has arrived (keeps the first generation's loads short)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            vb = *at(p.boards, i2); sb = *at(p.score, i2); ab = *at(p.actions, i2);
+        }
+        do_board<FLAGS>(p, i, va, sa, aa);
+        do_board<FLAGS>(p, i2, vb, sb, ab);
+        return;
     }
     if (!(FLAGS & F_PIPE)) {
         for (; i < p.n; i += stride) {
@@ -156,6 +179,9 @@ int main(int argc, char **argv)
         {"v10e full, LDS cap 2 blocks/CU", launch_lds<ALL | F_IDX64, 80000>, full},
         {"v10f compute only, LDS cap 4 blocks/CU", launch_lds<F_COMPUTE | F_SCORE, 40000>, full},
         {"v10g compute only, LDS cap 2 blocks/CU", launch_lds<F_COMPUTE | F_SCORE, 80000>, full},
+        {"v12a two boards/lane, both loads up front", launch<ALL | F_TWO>, full / 2},
+        {"v12b two boards/lane, B requested when A arrives", launch<ALL | F_TWO_LATE>, full / 2},
+        {"v12c two boards/lane, up front, 64-bit idx", launch<ALL | F_TWO | F_IDX64>, full / 2},
         {"v9a full, prio (blk>>8)&3", launch<ALL | F_PRIO8>, full},
         {"v9b full, prio (blk>>11)&3", launch<ALL | F_PRIO11>, full},
         {"v9c full, prio blk&3", launch<ALL | F_PRIOW>, full},
