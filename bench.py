@@ -164,7 +164,7 @@ def main():
         local = eng.last_scores()
         if backend != "nccl" and world > 1:        # gloo smoke test: collectives on host copies
             return allgather_returns(local.cpu(), shard)
-        return allgather_returns(local, shard)
+        return allgather_returns(local.clone(), shard)   # a torch-owned send buffer for RCCL
 
     # ---- warm-up: W untimed steps (own small buffers), then inputs for the timed K steps
     if W > 0:
