@@ -33,9 +33,6 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
         return static_cast<uint32_t>(static_cast<const long long *>(actions)[i]) & 3u;
 }
 
-// Episode bookkeeping.  Boards that ended an episode write their final score (and, if asked, their
-// terminal board); the wave's totals go to its WaveStats slot.  The whole block is skipped by a
-// wave-uniform branch when no lane terminated.
 // Wave-wide sum and max of a non-negative per-lane value, result valid in lane 63.  Seven DPP steps
 // each (row_shr 1,2,3,4,8 then row_bcast 15, 31): pure VALU, no LDS, no scalar loop.
 template <int CTRL, int ROW_MASK, int BANK_MASK>
@@ -44,20 +41,24 @@ __device__ __forceinline__ int dpp_shift(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
 }
 
-__device__ __forceinline__ void wave_sum_max(int v, int &sum, int &mx)
+__device__ __forceinline__ int wave_sum(int v) // result in lane 63
 {
     int s = v + dpp_shift<0x111, 0xf, 0xf>(v) + dpp_shift<0x112, 0xf, 0xf>(v) + dpp_shift<0x113, 0xf, 0xf>(v);
-    int m = max(max(v, dpp_shift<0x111, 0xf, 0xf>(v)), max(dpp_shift<0x112, 0xf, 0xf>(v), dpp_shift<0x113, 0xf, 0xf>(v)));
     s += dpp_shift<0x114, 0xf, 0xe>(s);
-    m = max(m, dpp_shift<0x114, 0xf, 0xe>(m));
     s += dpp_shift<0x118, 0xf, 0xc>(s);
-    m = max(m, dpp_shift<0x118, 0xf, 0xc>(m));
     s += dpp_shift<0x142, 0xa, 0xf>(s); // row_bcast:15 into rows 1 and 3
-    m = max(m, dpp_shift<0x142, 0xa, 0xf>(m));
     s += dpp_shift<0x143, 0xc, 0xf>(s); // row_bcast:31 into rows 2 and 3
+    return s;
+}
+
+__device__ __forceinline__ int wave_max(int v) // non-negative v; result broadcast to the whole wave
+{
+    int m = max(max(v, dpp_shift<0x111, 0xf, 0xf>(v)), max(dpp_shift<0x112, 0xf, 0xf>(v), dpp_shift<0x113, 0xf, 0xf>(v)));
+    m = max(m, dpp_shift<0x114, 0xf, 0xe>(m));
+    m = max(m, dpp_shift<0x118, 0xf, 0xc>(m));
+    m = max(m, dpp_shift<0x142, 0xa, 0xf>(m));
     m = max(m, dpp_shift<0x143, 0xc, 0xf>(m));
-    sum = s;
-    mx = m;
+    return __builtin_amdgcn_readlane(m, 63);
 }
 
 // Episode bookkeeping.  Boards that ended an episode write their final score (and, if asked, their
@@ -66,10 +67,13 @@ __device__ __forceinline__ void wave_sum_max(int v, int &sum, int &mx)
 struct WaveAcc {
     unsigned int episodes = 0, illegal_ends = 0;
     unsigned long long score_sum = 0; // valid in lane 63 only
-    int max_score = 0;                // valid in lane 63 only
+    int max_score = 0;                // wave-uniform
 };
 
-__device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, const StepResult &r, WaveAcc &acc)
+// `best_so_far`: the wave's recorded best final score (uniform).  The max reduction only runs when
+// some lane beats it, which after the first few hundred episodes of a wave practically never happens.
+__device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, const StepResult &r, WaveAcc &acc,
+                                                int best_so_far)
 {
     const unsigned long long done = __ballot(r.terminated);
     if (done == 0)
@@ -81,10 +85,10 @@ __device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, c
     }
     acc.episodes += static_cast<unsigned int>(__popcll(done));
     acc.illegal_ends += static_cast<unsigned int>(__popcll(__ballot(r.terminated && r.illegal)));
-    int sum, mx;
-    wave_sum_max(r.terminated ? r.terminal_score : 0, sum, mx);
-    acc.score_sum += static_cast<unsigned long long>(static_cast<long long>(sum));
-    acc.max_score = max(acc.max_score, mx);
+    const int v = r.terminated ? r.terminal_score : 0;
+    acc.score_sum += static_cast<unsigned long long>(static_cast<long long>(wave_sum(v)));
+    if (__ballot(v > max(best_so_far, acc.max_score)) != 0ull)
+        acc.max_score = max(acc.max_score, wave_max(v));
 }
 
 // The wave's slot is private to it (one wave per slot per launch, launches are stream-ordered), so
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
     }
     r.terminated = r.terminated && valid;
     WaveAcc acc;
-    record_episodes(p, i, r, acc);
+    record_episodes(p, i, r, acc, old_stats.max_score);
     flush_wave_stats(p, i_raw, old_stats, acc);
 }
 
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
                                       p.seed_lo, p.seed_hi);
         StepResult r = step_env(bd, score, w.w[3] >> 30, w, p.illegal_reward, p.max_exp, true);
         r.terminated = r.terminated && valid;
-        record_episodes(p, i, r, acc);
+        record_episodes(p, i, r, acc, 0);
     }
     if (valid) {
         p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
@@ -224,7 +228,7 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     }
     r.terminated = r.terminated && valid;
     WaveAcc acc;
-    record_episodes(p, i, r, acc);
+    record_episodes(p, i, r, acc, old_stats.max_score);
     flush_wave_stats(p, i_raw, old_stats, acc);
 }
 
