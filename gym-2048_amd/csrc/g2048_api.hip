@@ -118,7 +118,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     if (!out)
         return fail(G2048_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (n_boards == 0 || n_boards > 0xffffffffull || board_offset + n_boards > 0x100000000ull)
+    // (the launch grid is whole 256-lane blocks indexed in 32 bits, hence the 0xffffff00 cap)
+    if (n_boards == 0 || n_boards > 0xffffff00ull || board_offset + n_boards > 0x100000000ull)
         return fail(G2048_ERR_INVALID, "n_boards=%llu board_offset=%llu: global board indices must fit 32 bits",
                     (unsigned long long)n_boards, (unsigned long long)board_offset);
     int count = 0;

@@ -83,11 +83,13 @@ const char *g2048_last_error(void);
 int g2048_abi_version(void);
 
 /* Game2048Env.__init__ (game2048_env.py:38-58) for n_boards boards on HIP device `device`.
- * Boards are all-empty until g2048_reset.  board_offset = global index of local board 0. */
+ * Boards are all-empty until g2048_reset.  board_offset = global index of local board 0.
+ * 1 <= n_boards <= 2^32 - 256 and board_offset + n_boards <= 2^32. */
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out);
 int g2048_destroy(g2048_engine *e);
 
-/* gym.Env.reset(seed=...) seeding half (game2048_env.py:103): restart the spawn stream, t = 0. */
+/* gym.Env.reset(seed=...) seeding half (game2048_env.py:103): restart the spawn stream (t = 0) and
+ * clear the episode statistics (last_score, per-wave accumulators).  Synchronous (hipMemset). */
 int g2048_seed(g2048_engine *e, uint64_t seed);
 int g2048_get_clock(const g2048_engine *e, uint64_t *t);
 int g2048_set_clock(g2048_engine *e, uint64_t t);
