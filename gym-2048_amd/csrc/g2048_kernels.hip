@@ -112,7 +112,7 @@ __device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, 
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
-// One board per lane, one pass: load (board 16 B, score 4 B, action) -> ~330 VALU instructions ->
+// One board per lane, one pass: load (board 16 B, score 4 B, action) -> ~310 VALU instructions ->
 // store.  The Philox block does not depend on the loaded data, so its ~55 instructions run while
 // the loads are in flight.  Measured alternatives that were NOT faster on MI355X at 2^20 boards
 // (tools/ubench/step_variants.hip): grid-stride loops with the next board prefetched, per-block
