@@ -65,6 +65,16 @@ __device__ __forceinline__ void do_board(const Args &p, uint32_t i, uint4 v, int
     }
 }
 
+template <int FLAGS, int BS>
+__global__ void __launch_bounds__(BS) kern_bs(const Args p)
+{
+    const uint32_t i = blockIdx.x * BS + threadIdx.x;
+    if (i >= p.n) return;
+    const uint4 v = p.boards[i]; const int32_t sc = p.score[i]; const uint32_t a = p.actions[i];
+    do_board<FLAGS>(p, i, v, sc, a);
+}
+template <int FLAGS, int BS> void launch_bs(const Args &a, uint32_t) { hipLaunchKernelGGL((kern_bs<FLAGS, BS>), dim3((a.n + BS - 1) / BS), dim3(BS), 0, 0, a); }
+
 template <int FLAGS>
 __global__ void __launch_bounds__(256) kern(const Args p)
 {
@@ -182,6 +192,11 @@ int main(int argc, char **argv)
         {"v12a two boards/lane, both loads up front", launch<ALL | F_TWO>, full / 2},
         {"v12b two boards/lane, B requested when A arrives", launch<ALL | F_TWO_LATE>, full / 2},
         {"v12c two boards/lane, up front, 64-bit idx", launch<ALL | F_TWO | F_IDX64>, full / 2},
+        {"v13 block 64", launch_bs<ALL | F_IDX64, 64>, full},
+        {"v13 block 128", launch_bs<ALL | F_IDX64, 128>, full},
+        {"v13 block 256", launch_bs<ALL | F_IDX64, 256>, full},
+        {"v13 block 512", launch_bs<ALL | F_IDX64, 512>, full},
+        {"v13 block 1024", launch_bs<ALL | F_IDX64, 1024>, full},
         {"v9a full, prio (blk>>8)&3", launch<ALL | F_PRIO8>, full},
         {"v9b full, prio (blk>>11)&3", launch<ALL | F_PRIO11>, full},
         {"v9c full, prio blk&3", launch<ALL | F_PRIOW>, full},
