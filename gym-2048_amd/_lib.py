@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class G2048Error(RuntimeError):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "g2048_episode_stats": (C.c_int, [_E, C.POINTER(Stats), _S]),
     "g2048_set_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),
+    "g2048_seed_numpy": (C.c_int, [_E, _u64, _S]),
     "g2048_augment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _u64, C.c_void_p, C.c_void_p, C.c_void_p, _S]),
     "g2048_state_bytes": (_u64, [_E]),
     "g2048_get_state": (C.c_int, [_E, C.c_void_p, _S]),

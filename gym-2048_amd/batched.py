@@ -112,13 +112,13 @@ class Batched2048:
 
     def seed(self, seed: int):
         """Seeding half of ``reset(seed=...)`` (game2048_env.py:103)."""
-        check(self._lib.g2048_seed(self._h, int(seed) & (2**64 - 1)))
         self._fresh = True
         if self.rng_mode == "numpy":
-            # board i <- numpy PCG64(SeedSequence(seed + global index)), as gymnasium / SB3 seed env i
-            from .seeding import pcg64_planes
-            first = int(seed) + self.board_offset
-            self.set_numpy_rng(pcg64_planes(range(first, first + self.n_envs)))
+            # board i <- numpy PCG64(SeedSequence(seed + global index)), as gymnasium / SB3 seed env i;
+            # hashed and seeded on the device (g2048_pcg64.h), identical to numpy's own result
+            check(self._lib.g2048_seed_numpy(self._h, int(seed) & (2**64 - 1), self._stream()))
+        else:
+            check(self._lib.g2048_seed(self._h, int(seed) & (2**64 - 1)))
 
     def set_numpy_rng(self, planes):
         """Install per-board numpy PCG64 states (uint64 ``[5, n]``, see ``seeding.pcg64_planes``) and

@@ -111,7 +111,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 4; }
+int g2048_abi_version(void) { return 5; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -465,6 +465,22 @@ int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
         e->st.rng = static_cast<uint64_t *>(p);
     }
     return copy_in(e, e->st.rng, planes, e->n * 40, stream);
+}
+
+int g2048_seed_numpy(g2048_engine *e, uint64_t base_seed, void *stream)
+{
+    if (int rc = g2048_seed(e, base_seed))
+        return rc;
+    if (!e->st.rng) {
+        void *p = nullptr;
+        hipError_t err = hipMalloc(&p, e->n * 40);
+        if (err != hipSuccess)
+            return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)(e->n * 40), hipGetErrorString(err));
+        e->st.rng = static_cast<uint64_t *>(p);
+    }
+    G2048_HIP(g2048::launch_seed_numpy(e->st.rng, static_cast<uint32_t>(e->n), base_seed + e->board_offset,
+                                       static_cast<hipStream_t>(stream)));
+    return G2048_OK;
 }
 
 int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream)

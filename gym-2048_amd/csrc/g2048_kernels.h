@@ -62,6 +62,7 @@ hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8
                         hipStream_t s);
 hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s);
 // the same three in numpy-RNG mode (a.st.rng != NULL)
+hipError_t launch_seed_numpy(uint64_t *planes, uint32_t n, uint64_t first_seed, hipStream_t s);
 hipError_t launch_reset_numpy(const StepArgs &a, const uint8_t *mask, hipStream_t s);
 hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s);
 hipError_t launch_add_tile_numpy(const StepArgs &a, hipStream_t s);

@@ -232,6 +232,20 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     flush_wave_stats(p, i_raw, old_stats, acc);
 }
 
+// numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.
+__global__ void __launch_bounds__(kBlock) seed_numpy_kernel(uint64_t *planes, uint32_t n, uint64_t first_seed)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const Pcg64 r = pcg64_from_seed(first_seed + i);
+    planes[i] = r.state_lo;
+    planes[n + i] = r.state_hi;
+    planes[2ull * n + i] = r.inc_lo;
+    planes[3ull * n + i] = r.inc_hi;
+    planes[4ull * n + i] = r.buf;
+}
+
 __global__ void __launch_bounds__(kBlock) reset_numpy_kernel(const StepArgs p, const uint8_t *mask)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -548,6 +562,14 @@ hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s)
     if (a.n == 0)
         return hipSuccess;
     hipLaunchKernelGGL(add_tile_kernel, grid_for(a.n), dim3(kBlock), 0, s, a, slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_numpy(uint64_t *planes, uint32_t n, uint64_t first_seed, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(seed_numpy_kernel, grid_for(n), dim3(kBlock), 0, s, planes, n, first_seed);
     return hipGetLastError();
 }
 

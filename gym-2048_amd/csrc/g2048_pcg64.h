@@ -132,3 +132,74 @@ G2048_DEV StepResult step_env_numpy(Board &bd, int32_t &score, uint32_t action, 
 }
 
 } // namespace g2048
+
+// ------------------------------------------------------------------------------- device seeding
+// numpy.random.SeedSequence(entropy).generate_state(4, uint64) followed by PCG64's seeding, for an
+// integer entropy < 2^64 and an empty spawn key [numpy random/bit_generator.pyx: SeedSequence
+// mix_entropy / generate_state; _pcg64.pyx _seed -> pcg64_set_seed -> pcg_setseq_128_srandom_r].
+// Lets an engine seed a million boards (seed + i) on the device instead of looping over numpy on the
+// host.  Pinned against numpy by tests/test_numpy_rng.py.
+namespace g2048 {
+
+G2048_DEV uint32_t ss_hashmix(uint32_t value, uint32_t &hash_const)
+{
+    value ^= hash_const;
+    hash_const *= 0x931e8875u; // MULT_A
+    value *= hash_const;
+    value ^= value >> 16;
+    return value;
+}
+
+G2048_DEV uint32_t ss_mix(uint32_t x, uint32_t y)
+{
+    uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; // MIX_MULT_L, MIX_MULT_R
+    r ^= r >> 16;
+    return r;
+}
+
+G2048_DEV Pcg64 pcg64_from_seed(uint64_t entropy)
+{
+    // entropy as little-endian uint32 words: one word below 2^32, else two (numpy's _coerce_to_uint32_array)
+    const uint32_t e0 = (uint32_t)entropy, e1 = (uint32_t)(entropy >> 32);
+    const int n_words = e1 != 0u ? 2 : 1;
+    uint32_t pool[4];
+    uint32_t hash_const = 0x43b0d7e5u; // INIT_A
+    pool[0] = ss_hashmix(e0, hash_const);
+    pool[1] = ss_hashmix(n_words > 1 ? e1 : 0u, hash_const);
+    pool[2] = ss_hashmix(0u, hash_const);
+    pool[3] = ss_hashmix(0u, hash_const);
+#pragma unroll
+    for (int src = 0; src < 4; ++src)
+#pragma unroll
+        for (int dst = 0; dst < 4; ++dst)
+            if (src != dst)
+                pool[dst] = ss_mix(pool[dst], ss_hashmix(pool[src], hash_const));
+    // generate_state(4, uint64) = 8 uint32 words cycling through the pool
+    uint32_t w[8];
+    uint32_t hc = 0x8b51f9ddu; // INIT_B
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i & 3] ^ hc;
+        hc *= 0x58f38dedu; // MULT_B
+        v *= hc;
+        v ^= v >> 16;
+        w[i] = v;
+    }
+    const uint64_t s0 = w[0] | ((uint64_t)w[1] << 32), s1 = w[2] | ((uint64_t)w[3] << 32);
+    const uint64_t s2 = w[4] | ((uint64_t)w[5] << 32), s3 = w[6] | ((uint64_t)w[7] << 32);
+    // pcg64_set_seed: initstate = (high s0, low s1), initseq = (high s2, low s3)
+    Pcg64 r;
+    r.inc_lo = (s3 << 1) | 1ull;               // inc = (initseq << 1) | 1
+    r.inc_hi = (s2 << 1) | (s3 >> 63);
+    r.state_lo = 0;
+    r.state_hi = 0;
+    r.buf = 0;
+    (void)pcg64_next64(r);                     // step
+    const uint64_t lo = r.state_lo + s1;       // state += initstate
+    r.state_hi += s0 + (lo < r.state_lo ? 1ull : 0ull);
+    r.state_lo = lo;
+    (void)pcg64_next64(r);                     // step
+    return r;
+}
+
+} // namespace g2048

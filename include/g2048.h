@@ -175,6 +175,10 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
  * About 5x slower than the spawn stream; g2048_rollout_random is not available in this mode. */
 int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream);
 int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream);
+/* The same mode, seeded on the device: board i <- numpy PCG64(SeedSequence(base_seed + board_offset + i))
+ * (SeedSequence hashing + PCG64 seeding restated in g2048_pcg64.h, pinned against numpy).  Also does
+ * what g2048_seed does (t = 0, statistics cleared). */
+int g2048_seed_numpy(g2048_engine *e, uint64_t base_seed, void *stream);
 
 /* training_data.augment() (training_data.py:257-299) on the current device: n transitions
  * (boards[n][16], optional next_boards[n][16], actions uint8[n]; device pointers, 16-byte aligned) ->

@@ -125,6 +125,7 @@ static void store_rng(g2048o_pcg64 *r, const Pcg64 &p)
 uint64_t hostcheck_pcg64_next64(g2048o_pcg64 *r) { Pcg64 p = load_rng(r); const uint64_t v = pcg64_next64(p); store_rng(r, p); return v; }
 uint32_t hostcheck_pcg64_next32(g2048o_pcg64 *r) { Pcg64 p = load_rng(r); const uint32_t v = pcg64_next32(p); store_rng(r, p); return v; }
 uint32_t hostcheck_pcg64_interval(g2048o_pcg64 *r, uint32_t mx) { Pcg64 p = load_rng(r); const uint32_t v = pcg64_interval(p, mx); store_rng(r, p); return v; }
+void hostcheck_pcg64_from_seed(uint64_t entropy, g2048o_pcg64 *out) { store_rng(out, pcg64_from_seed(entropy)); }
 uint32_t hostcheck_empty_mask16(const uint8_t b[16]) { return empty_mask16(load_board(b)); }
 
 void hostcheck_reset_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, uint64_t t, int)

@@ -373,7 +373,10 @@ def test_numpy_rng_mode_vs_oracle_and_generator_state(torch_cuda):
     eng = Batched2048(n, seed=seed, rng="numpy")
     ob = OracleBatch(n, seed, threads=0)
     ob.seed_numpy(seed)
-    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)          # device seeding == numpy's SeedSequence/PCG64
+    from gym2048_amd.seeding import pcg64_planes
+    big = Batched2048(3, seed=2 ** 40 + 7, board_offset=100, rng="numpy")  # entropy >= 2^32: two words
+    assert np.array_equal(big.get_numpy_rng(), pcg64_planes([2 ** 40 + 107, 2 ** 40 + 108, 2 ** 40 + 109]))
     eng.reset()
     ob.reset_numpy()
     for s in range(48):

@@ -158,3 +158,14 @@ def test_device_header_pcg64_and_rollout_vs_oracle(host_check, oracle_lib):
         y.step(None)
         for f in ("boards", "score", "reward", "terminated", "illegal", "highest", "rng"):
             assert np.array_equal(getattr(x, f), getattr(y, f)), (f, s)
+
+
+def test_device_seeding_matches_numpy_seedsequence(host_check):
+    """pcg64_from_seed (the device header's SeedSequence + PCG64 seeding) == numpy, incl. seeds >= 2^32."""
+    seeds = list(range(0, 300)) + [2 ** 31 - 1, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 5, 2 ** 40 + 12345, 2 ** 63 + 99,
+                                   2 ** 64 - 1] + [int(x) for x in np.random.default_rng(1).integers(0, 2 ** 62, 200)]
+    want = pcg64_states_from_seeds(seeds)
+    got = np.zeros(5, np.uint64)
+    for s, w in zip(seeds, want):
+        host_check.hostcheck_pcg64_from_seed(C.c_uint64(s), C.c_void_p(got.ctypes.data))
+        assert np.array_equal(got, w), s
