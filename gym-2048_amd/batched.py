@@ -317,6 +317,9 @@ class Batched2048:
 
     def load_state_dict(self, state: dict):
         blob = np.ascontiguousarray(state["blob"], dtype=np.uint8)
+        base = self._lib.g2048_state_bytes(self._h) - (40 * self.n_envs if self.rng_mode == "numpy" else 0)
+        if blob.size not in (base, base + 40 * self.n_envs):
+            raise ValueError("state blob size does not match this engine")
         check(self._lib.g2048_set_state(self._h, blob.ctypes.data, self._stream()))
         self._fresh = bool(state.get("fresh", False))
         self.rng_mode = state.get("rng_mode", "philox")
