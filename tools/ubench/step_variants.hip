@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(BS) kern_bs(const Args p)
     do_board<FLAGS>(p, i, v, sc, a);
 }
 // cache-policy variants: NT loads and/or NT stores (nt=1 hint)
-template <int NTL, int NTS>
+template <int NTL, int NTS, int SCORE = 1>
 __global__ void __launch_bounds__(256) kern_nt(const Args p)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) kern_nt(const Args p)
         const uint32_t *bp = reinterpret_cast<const uint32_t *>(p.boards + i);
         v.x = __builtin_nontemporal_load(bp); v.y = __builtin_nontemporal_load(bp + 1);
         v.z = __builtin_nontemporal_load(bp + 2); v.w = __builtin_nontemporal_load(bp + 3);
-        sc = __builtin_nontemporal_load(p.score + i); a = __builtin_nontemporal_load(p.actions + i);
+        sc = SCORE ? __builtin_nontemporal_load(p.score + i) : 0; a = __builtin_nontemporal_load(p.actions + i);
     } else { v = p.boards[i]; sc = p.score[i]; a = p.actions[i]; }
     Board bd{{v.x, v.y, v.z, v.w}};
     int32_t score = sc;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) kern_nt(const Args p)
         uint32_t *bp = reinterpret_cast<uint32_t *>(p.boards + i);
         __builtin_nontemporal_store(bd.r[0], bp); __builtin_nontemporal_store(bd.r[1], bp + 1);
         __builtin_nontemporal_store(bd.r[2], bp + 2); __builtin_nontemporal_store(bd.r[3], bp + 3);
-        __builtin_nontemporal_store(score, p.score + i);
+        if (SCORE) __builtin_nontemporal_store(score, p.score + i);
         __builtin_nontemporal_store(r.reward, p.reward + i);
         __builtin_nontemporal_store((uint8_t)r.terminated, p.terminated + i);
     } else {
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) kern_nt(const Args p)
     }
     if (__ballot(r.terminated) && r.terminated) p.last_score[i] = r.terminal_score;
 }
-template <int NTL, int NTS> void launch_nt(const Args &a, uint32_t blocks) { hipLaunchKernelGGL((kern_nt<NTL, NTS>), dim3(blocks), dim3(256), 0, 0, a); }
+template <int NTL, int NTS, int SCORE = 1> void launch_nt(const Args &a, uint32_t blocks) { hipLaunchKernelGGL((kern_nt<NTL, NTS, SCORE>), dim3(blocks), dim3(256), 0, 0, a); }
 
 template <int FLAGS, int BS> void launch_bs(const Args &a, uint32_t) { hipLaunchKernelGGL((kern_bs<FLAGS, BS>), dim3((a.n + BS - 1) / BS), dim3(BS), 0, 0, a); }
 
@@ -227,6 +227,7 @@ int main(int argc, char **argv)
         {"v14 nt loads, plain stores", launch_nt<1, 0>, full},
         {"v14 plain loads, nt stores", launch_nt<0, 1>, full},
         {"v14 nt loads, nt stores", launch_nt<1, 1>, full},
+        {"v14 nt loads, nt stores, NO score array", launch_nt<1, 1, 0>, full},
         {"v13 block 64", launch_bs<ALL | F_IDX64, 64>, full},
         {"v13 block 128", launch_bs<ALL | F_IDX64, 128>, full},
         {"v13 block 256", launch_bs<ALL | F_IDX64, 256>, full},
