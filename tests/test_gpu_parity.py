@@ -419,3 +419,30 @@ def test_single_env_numpy_mode_is_the_reference_env(torch_cuda):
         if term:
             env.reset()
         assert np.array_equal(env.get_board(), vals(d["boards"][0, s]))
+
+
+def test_argument_validation_on_device(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    e = Batched2048(128, seed=1)
+    e.reset()
+    with pytest.raises(TypeError):
+        e.step(torch.zeros(128, dtype=torch.float32))
+    with pytest.raises(ValueError):
+        e.step(torch.zeros(127, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        e.rollout(torch.zeros((4, 128), dtype=torch.uint8), reward=torch.zeros((3, 128), device=e.device))
+    with pytest.raises(ValueError):
+        e.observe_onehot(out=torch.zeros((128, 16, 4, 4), dtype=torch.int32, device=e.device))
+    with pytest.raises(ValueError):
+        Batched2048(8, rng="mt19937")
+    with pytest.raises(ValueError):
+        e.load_state_dict({"blob": np.zeros(10, np.uint8)})
+    boards = e.get_boards()
+    e.step(torch.full((128,), 7, dtype=torch.int64))            # only the low two bits count: 7 == left
+    f = Batched2048(128, seed=1)
+    f.reset()
+    f.step(torch.full((128,), 3, dtype=torch.uint8))
+    assert np.array_equal(e.get_boards(), f.get_boards()) and not np.array_equal(e.get_boards(), boards)
+    e.close()
+    e.close()                                                    # idempotent

@@ -102,6 +102,37 @@ __global__ void __launch_bounds__(256) kern_nt(const Args p)
     }
     if (__ballot(r.terminated) && r.terminated) p.last_score[i] = r.terminal_score;
 }
+// two boards per lane (i and i + n/2), all nt, both loads up front
+template <int NB>
+__global__ void __launch_bounds__(256) kern_nt_multi(const Args p)
+{
+    const uint32_t i0 = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t part = p.n / NB;
+    if (i0 >= part) return;
+    u32x4 v[NB]; int32_t sc[NB]; uint32_t a[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t i = i0 + k * part;
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.boards) + i);
+        sc[k] = __builtin_nontemporal_load(p.score + i); a[k] = __builtin_nontemporal_load(p.actions + i);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t i = i0 + k * part;
+        Board bd{{v[k].x, v[k].y, v[k].z, v[k].w}};
+        int32_t score = sc[k];
+        const Words w = philox4x32_10(p.t_lo, 0u, i, 0u, p.seed_lo, p.seed_hi);
+        const StepResult r = step_env(bd, score, a[k] & 3u, w, 0.0f, 0u, true);
+        const u32x4 o = {bd.r[0], bd.r[1], bd.r[2], bd.r[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(p.boards) + i);
+        __builtin_nontemporal_store(score, p.score + i);
+        __builtin_nontemporal_store(r.reward, p.reward + i);
+        __builtin_nontemporal_store((uint8_t)r.terminated, p.terminated + i);
+        if (__ballot(r.terminated) && r.terminated) p.last_score[i] = r.terminal_score;
+    }
+}
+template <int NB> void launch_nt_multi(const Args &a, uint32_t blocks) { hipLaunchKernelGGL((kern_nt_multi<NB>), dim3((blocks + NB - 1) / NB), dim3(256), 0, 0, a); }
+
 template <int NTL, int NTS, int SCORE = 1> void launch_nt(const Args &a, uint32_t blocks) { hipLaunchKernelGGL((kern_nt<NTL, NTS, SCORE>), dim3(blocks), dim3(256), 0, 0, a); }
 
 template <int FLAGS, int BS> void launch_bs(const Args &a, uint32_t) { hipLaunchKernelGGL((kern_bs<FLAGS, BS>), dim3((a.n + BS - 1) / BS), dim3(BS), 0, 0, a); }
@@ -228,6 +259,8 @@ int main(int argc, char **argv)
         {"v14 plain loads, nt stores", launch_nt<0, 1>, full},
         {"v14 nt loads, nt stores", launch_nt<1, 1>, full},
         {"v14 nt loads, nt stores, NO score array", launch_nt<1, 1, 0>, full},
+        {"v15 nt, 2 boards per lane", launch_nt_multi<2>, full},
+        {"v15 nt, 4 boards per lane", launch_nt_multi<4>, full},
         {"v13 block 64", launch_bs<ALL | F_IDX64, 64>, full},
         {"v13 block 128", launch_bs<ALL | F_IDX64, 128>, full},
         {"v13 block 256", launch_bs<ALL | F_IDX64, 256>, full},
