@@ -446,3 +446,28 @@ def test_argument_validation_on_device(torch_cuda):
     assert np.array_equal(e.get_boards(), f.get_boards()) and not np.array_equal(e.get_boards(), boards)
     e.close()
     e.close()                                                    # idempotent
+
+
+def test_full_size_conservation_over_a_rollout(torch_cuda):
+    """2^20 boards x 200 steps through g2048_rollout: a checksum of checksums ties every output together --
+    episodes == number of terminated flags; sum of all rewards == score_sum of finished episodes + the
+    scores still running (illegal_move_reward = 0); illegal_ends <= episodes; and the whole run is
+    reproduced bit for bit by a second engine (determinism at full size)."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    n, k = 1 << 20, 200
+    a, b = Batched2048(n, seed=42), Batched2048(n, seed=42)
+    for e in (a, b):
+        e.reset()
+    acts = a.random_actions(k)
+    rew = torch.zeros((k, n), dtype=torch.float32, device=a.device)
+    term = torch.zeros((k, n), dtype=torch.uint8, device=a.device)
+    a.rollout(acts, reward=rew, terminated=term)
+    b.rollout(acts)
+    st = a.episode_stats()
+    assert st["episodes"] == int(term.sum(dtype=torch.int64))
+    assert int(rew.sum(dtype=torch.float64)) == st["score_sum"] + int(a.scores().sum(dtype=torch.int64))
+    assert 0 < st["illegal_ends"] <= st["episodes"] and st["max_score"] >= st["mean_score"] > 0
+    assert torch.equal(a.boards(), b.boards()) and torch.equal(a.scores(), b.scores())
+    assert st == b.episode_stats() and a.clock == b.clock == k
+    assert torch.equal(a.last_scores(), b.last_scores())
