@@ -327,11 +327,19 @@ class Batched2048:
     # ------------------------------------------------------------------ numpy facade (used by the
     # single-env and VecEnv adapters; tests replace this object by an oracle-backed fake)
     def step_numpy(self, actions, auto_reset: bool = True) -> dict:
+        """Step with host actions and bring every per-step output back in ONE device-to-host copy
+        (reward, terminated, illegal, highest, terminal boards, boards after the step)."""
         a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int64))
         self.step(a, auto_reset=auto_reset, want_info=True)
-        out = torch.stack([self.terminated, self.illegal, self.highest]).cpu().numpy()
-        return dict(reward=self.reward.cpu().numpy(), terminated=out[0].astype(bool), illegal=out[1].astype(bool),
-                    highest=out[2], terminal_boards=self.terminal_boards.cpu().numpy().reshape(-1, 4, 4))
+        n = self.n_envs
+        packed = torch.cat([self.reward.view(torch.uint8), self.terminated, self.illegal, self.highest,
+                            self.terminal_boards.reshape(-1), self.boards().reshape(-1)]).cpu().numpy()
+        off = 4 * n
+        return dict(reward=packed[:off].view(np.float32).copy(),
+                    terminated=packed[off:off + n].astype(bool), illegal=packed[off + n:off + 2 * n].astype(bool),
+                    highest=packed[off + 2 * n:off + 3 * n].copy(),
+                    terminal_boards=packed[off + 3 * n:off + 19 * n].reshape(n, 4, 4).copy(),
+                    boards=packed[off + 19 * n:off + 35 * n].reshape(n, 4, 4).copy())
 
     def onehot_numpy(self) -> np.ndarray:
         return self.observe_onehot(torch.uint8).cpu().numpy()

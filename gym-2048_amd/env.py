@@ -110,8 +110,9 @@ class Game2048Env:
             reward = float(res["reward"][0])
             self.score += reward
             self._slot = 1
-        info["highest"] = self.highest()
-        return self._obs(), reward, bool(res["terminated"][0]), False, info
+        board = _exp_to_values(res["boards"][0])          # came back with the step's single copy
+        info["highest"] = np.max(board)                   # :97
+        return stack(board), reward, bool(res["terminated"][0]), False, info
 
     def reset(self, seed=None, options=None):
         """game2048_env.py:102-111."""

@@ -39,7 +39,8 @@ class OracleEngine:
         self.ob.step(np.asarray(actions) & 3, auto_reset=auto_reset)
         o = self.ob
         return dict(reward=o.reward.copy(), terminated=o.terminated.astype(bool), illegal=o.illegal.astype(bool),
-                    highest=o.highest.copy(), terminal_boards=o.terminal_boards.reshape(-1, 4, 4).copy())
+                    highest=o.highest.copy(), terminal_boards=o.terminal_boards.reshape(-1, 4, 4).copy(),
+                    boards=o.boards.reshape(-1, 4, 4).copy())
 
     # observations / state
     def get_boards(self):
