@@ -84,10 +84,19 @@ G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
 {
     const uint32_t exp = ((pcg64_next64(r) >> 11) < kTwoThreshold53) ? 1u : 2u; // :168
     uint64_t pos = 0xFEDCBA9876543210ull;                                       // :169 nibble i = position i
-    for (uint32_t i = 15; i >= 1; --i) {                                        // :170 Generator.shuffle
-        const uint32_t j = pcg64_interval(r, i);
-        const uint64_t d = ((pos >> (4u * i)) ^ (pos >> (4u * j))) & 15ull;     // swap nibbles i and j
-        pos ^= (d << (4u * i)) | (d << (4u * j));
+    // :170 Generator.shuffle: for i = 15 .. 1: j = random_interval(i); swap(pos[i], pos[j]).  Written as
+    // ONE loop over 32-bit draws in which every lane keeps its own i: a lane whose masked draw is
+    // rejected (v > i) simply keeps i for the next draw.  The draws each lane consumes are exactly
+    // numpy's, but the wavefront iterates max-over-lanes of the TOTAL draws (~30) instead of the sum over
+    // i of max-over-lanes of the per-i rejections (~60).
+    for (uint32_t i = 15; i >= 1;) {
+        const uint32_t mask = i >= 8u ? 15u : (i >= 4u ? 7u : (i >= 2u ? 3u : 1u));
+        const uint32_t j = pcg64_next32(r) & mask;
+        if (j <= i) {
+            const uint64_t d = ((pos >> (4u * i)) ^ (pos >> (4u * j))) & 15ull; // swap nibbles i and j
+            pos ^= (d << (4u * i)) | (d << (4u * j));
+            --i;
+        }
     }
     const uint32_t empty = empty_mask16(bd);
     uint32_t p = 0;
