@@ -10,7 +10,8 @@ mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 BENCH="python bench.py --steps 200 --warmup 20 --no-extras $*"
-rocprofv3 --kernel-trace --stats -d $O/stats -o r -- $BENCH > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/stats -o r -- $BENCH > $O/stats.log 2>&1
+cp $O/stats/r_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/pmc_sq1 -o r -- $BENCH > $O/pmc_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $O/pmc_sq2 -o r -- $BENCH > $O/pmc_sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- $BENCH > $O/pmc_fetch.log 2>&1
