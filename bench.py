@@ -206,7 +206,7 @@ def main():
     traffic = load_traffic()
 
     out = {
-        "metric": "env-steps/sec at batch=2^20 per MI355X", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "metric": ("env-steps/sec at batch=2^20 per MI355X" if B == (1 << 20) else f"env-steps/sec at batch={B} per MI355X"), "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"batch={B} envs per GPU, random-policy rollout, int8 boards (BASELINE configs[2])",
