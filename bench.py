@@ -233,6 +233,15 @@ def main():
         eng.rollout_random(kf)
         torch.cuda.synchronize()
         extras["fused_rollout_steps_per_s"] = kf * B / (time.perf_counter() - t1)
+        # (a2) the SAME rollout as the timed region (same actions, same [K][B] outputs) as ONE fused launch
+        try:
+            kf2 = min(K, 256)
+            t1 = time.perf_counter()
+            eng.rollout(actions[:kf2], reward=reward[:kf2], terminated=terminated[:kf2], fused=True)
+            torch.cuda.synchronize()
+            extras["fused_rollout_with_io_steps_per_s"] = kf2 * B / (time.perf_counter() - t1)
+        except Exception as exc:  # pragma: no cover
+            extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
         # (b) a batch that does not fit L2 + Infinity Cache: 2^24 boards (256 MiB of boards)
         del reward, terminated, actions
         try:

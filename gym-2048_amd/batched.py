@@ -199,9 +199,11 @@ class Batched2048:
         self._fresh = False
         return self.reward, self.terminated
 
-    def rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None, auto_reset: bool = True):
+    def rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None, auto_reset: bool = True,
+                fused: bool = False):
         """``k`` steps without returning to Python: ``actions`` is ``[k, n]`` (or ``k`` as an int for
-        the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers."""
+        the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers.  ``fused=True``
+        runs them as ONE launch with the boards in registers (same outputs, ``g2048_rollout_fused``)."""
         if isinstance(actions, int):
             k, act = actions, None
         else:
@@ -213,7 +215,8 @@ class Batched2048:
             if t is not None and (t.shape != (k, self.n_envs) or not t.is_contiguous() or t.device != self.device):
                 raise ValueError("rollout buffers must be contiguous [k, n_envs] tensors on the engine's device")
         io = self._io(act, reward, terminated, illegal, highest, None)
-        check(self._lib.g2048_rollout(self._h, k, C.byref(io), self.n_envs, int(auto_reset), self._stream()))
+        fn = self._lib.g2048_rollout_fused if fused else self._lib.g2048_rollout
+        check(fn(self._h, k, C.byref(io), self.n_envs, int(auto_reset), self._stream()))
         self._fresh = False
 
     def rollout_random(self, k_steps: int):

@@ -111,7 +111,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 5; }
+int g2048_abi_version(void) { return 6; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -296,6 +296,29 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         else
             G2048_HIP(g2048::launch_step(a, s.action_dtype, static_cast<hipStream_t>(stream)));
     }
+    return G2048_OK;
+}
+
+int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
+                        void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = check_io(io))
+        return rc;
+    if (io->terminal_boards)
+        return fail(G2048_ERR_INVALID, "g2048_rollout_fused does not write terminal_boards");
+    if (e->st.rng)
+        return fail(G2048_ERR_INVALID, "g2048_rollout_fused draws from the spawn stream; not available in numpy-RNG mode");
+    if (k_steps == 0)
+        return G2048_OK;
+    G2048_HIP(hipSetDevice(e->device));
+    e->t += 1; // transaction of the first fused step
+    e->fresh = 0;
+    g2048::StepArgs a = make_args(e, io, auto_reset);
+    a.k_steps = k_steps;
+    G2048_HIP(g2048::launch_rollout_fused(a, io->action_dtype, stride, static_cast<hipStream_t>(stream)));
+    e->t += k_steps - 1;
     return G2048_OK;
 }
 

@@ -56,6 +56,7 @@ struct StatsOut {
 hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s);
 hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s);
 hipError_t launch_rollout_random(const StepArgs &a, hipStream_t s);
+hipError_t launch_rollout_fused(const StepArgs &a, int action_dtype, uint64_t stride, hipStream_t s);
 hipError_t launch_move(uint4 *boards, uint32_t n, const void *actions, int action_dtype, bool trial,
                        int32_t *score_out, uint8_t *legal_out, hipStream_t s);
 hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8_t *isend_out, uint8_t *highest_out,

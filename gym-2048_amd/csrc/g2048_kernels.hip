@@ -198,6 +198,55 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     flush_wave_stats(p, i_raw, p.st.wave_stats[i_raw >> 6], acc);
 }
 
+// ---------------------------------------------------------------- fused rollout with per-step I/O
+// The same k steps g2048_rollout performs with k launches, in ONE launch: boards and scores stay in
+// registers, each step reads action[j][i] and writes reward[j][i] / terminated[j][i] (stride = elements
+// between consecutive steps).  Bit-identical outputs; 6 B of traffic per env-step instead of 46.
+template <int ACT>
+__global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p, uint64_t stride)
+{
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
+    Board bd = load_board_nt(p.st.boards, i);
+    int32_t score = p.st.score[i];
+    const WaveStats old_stats = p.st.wave_stats[i_raw >> 6];
+    uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
+    WaveAcc acc;
+    for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
+        const size_t o = static_cast<size_t>(j) * stride + i;
+        const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
+                                      p.seed_lo, p.seed_hi);
+        uint32_t action;
+        if constexpr (ACT == 0)
+            action = w.w[3] >> 30;
+        else if constexpr (ACT == 1)
+            action = __builtin_nontemporal_load(static_cast<const uint8_t *>(p.actions) + o) & 3u;
+        else if constexpr (ACT == 2)
+            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(p.actions) + o)) & 3u;
+        else
+            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(p.actions) + o)) & 3u;
+        StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+        if (valid) {
+            if (p.reward)
+                __builtin_nontemporal_store(r.reward, p.reward + o);
+            if (p.terminated)
+                __builtin_nontemporal_store(static_cast<uint8_t>(r.terminated ? 1 : 0), p.terminated + o);
+            if (p.illegal)
+                __builtin_nontemporal_store(static_cast<uint8_t>(r.illegal ? 1 : 0), p.illegal + o);
+            if (p.highest)
+                __builtin_nontemporal_store(static_cast<uint8_t>(highest(r.terminal)), p.highest + o);
+        }
+        r.terminated = r.terminated && valid;
+        record_episodes(p, i, r, acc, max(old_stats.max_score, acc.max_score));
+    }
+    if (valid) {
+        store_board_nt(p.st.boards, i, bd);
+        p.st.score[i] = score;
+    }
+    flush_wave_stats(p, i_raw, old_stats, acc);
+}
+
 // ------------------------------------------------------------------------- numpy-RNG mode
 // Same step / reset / add_tile, drawing from each board's own PCG64 exactly as numpy would
 // (g2048_pcg64.h).  RNG state: five coalesced 8-byte planes.
@@ -620,6 +669,21 @@ hipError_t launch_add_tile_numpy(const StepArgs &a, hipStream_t s)
     if (a.n == 0)
         return hipSuccess;
     hipLaunchKernelGGL(add_tile_numpy_kernel, grid_for(a.n), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_fused(const StepArgs &a, int action_dtype, uint64_t stride, hipStream_t s)
+{
+    if (a.n == 0 || a.k_steps == 0)
+        return hipSuccess;
+    const dim3 g = grid_for(a.n), b(kBlock);
+    switch (action_dtype) {
+    case 0: hipLaunchKernelGGL(rollout_fused_kernel<0>, g, b, 0, s, a, stride); break;
+    case 1: hipLaunchKernelGGL(rollout_fused_kernel<1>, g, b, 0, s, a, stride); break;
+    case 2: hipLaunchKernelGGL(rollout_fused_kernel<2>, g, b, 0, s, a, stride); break;
+    case 3: hipLaunchKernelGGL(rollout_fused_kernel<3>, g, b, 0, s, a, stride); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

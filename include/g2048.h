@@ -117,6 +117,14 @@ int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *s
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream);
 
+/* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /
+ * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead
+ * of 46).  For action sequences that are known in advance (replays, scripted or tree-search rollouts);
+ * a policy that needs every observation uses g2048_step / g2048_rollout.  terminal_boards must be
+ * NULL; not available in numpy-RNG mode. */
+int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
+                        void *stream);
+
 /* ONE launch that plays k steps of the synthetic random policy with boards held in registers
  * (auto-reset on).  Writes only the final state and the episode bookkeeping. */
 int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream);

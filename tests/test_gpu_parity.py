@@ -203,20 +203,24 @@ def test_rollout_paths_agree(torch_cuda):
     torch = torch_cuda
     from gym2048_amd.batched import Batched2048
     n, k, seed = 20000, 50, 99
-    a, b, c = (Batched2048(n, seed=seed) for _ in range(3))
-    for e in (a, b, c):
+    a, b, c, d = (Batched2048(n, seed=seed) for _ in range(4))
+    for e in (a, b, c, d):
         e.reset()
     acts = a.random_actions(k)
     rew = torch.zeros((k, n), dtype=torch.float32, device=a.device)
     term = torch.zeros((k, n), dtype=torch.uint8, device=a.device)
     a.rollout(acts, reward=rew, terminated=term)
     b.rollout_random(k)
+    rew_f, term_f = torch.zeros_like(rew), torch.zeros_like(term)
+    ill_f = torch.zeros_like(term)
+    d.rollout(acts.to(torch.int64), reward=rew_f, terminated=term_f, illegal=ill_f, fused=True)  # one launch
+    assert torch.equal(rew_f, rew) and torch.equal(term_f, term) and bool((ill_f <= term_f).all())
     rewards, terms = [], []
     for j in range(k):
         c.step(None)
         rewards.append(c.reward.clone())
         terms.append(c.terminated.clone())
-    for e in (a, b):
+    for e in (a, b, d):
         assert np.array_equal(e.get_boards(), c.get_boards())
         assert np.array_equal(e.get_scores(), c.get_scores())
         assert np.array_equal(e.get_last_scores(), c.get_last_scores())
