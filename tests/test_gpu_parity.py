@@ -475,3 +475,46 @@ def test_full_size_conservation_over_a_rollout(torch_cuda):
     assert torch.equal(a.boards(), b.boards()) and torch.equal(a.scores(), b.scores())
     assert st == b.episode_stats() and a.clock == b.clock == k
     assert torch.equal(a.last_scores(), b.last_scores())
+
+
+@pytest.mark.parametrize("max_tile,auto_reset,irw", [(64, True, -1.0), (None, False, 0.0)])
+def test_numpy_rng_mode_config_variants_vs_oracle(torch_cuda, max_tile, auto_reset, irw):
+    """numpy-RNG mode with max_tile / without auto-reset / with an illegal-move penalty, int32 actions,
+    and a masked reset in the middle -- all against the C oracle's numpy mode."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed = 1500, 77
+    eng = Batched2048(n, seed=seed, rng="numpy", illegal_move_reward=irw, max_tile=max_tile)
+    ob = OracleBatch(n, seed, threads=0)
+    ob.illegal_move_reward = irw
+    ob.max_exp = int(np.log2(max_tile)) if max_tile else 0
+    ob.seed_numpy(seed)
+    eng.reset()
+    ob.reset_numpy()
+    rng = np.random.default_rng(3)
+    for s in range(60):
+        acts = rng.integers(0, 4, n).astype(np.int32)
+        eng.step(torch.as_tensor(acts), auto_reset=auto_reset)
+        ob.step_numpy(acts.astype(np.uint8), auto_reset=auto_reset)
+        assert np.array_equal(eng.get_boards().reshape(n, 16), ob.boards), s
+        assert np.array_equal(eng.reward.cpu().numpy(), ob.reward)
+        assert np.array_equal(eng.terminated.cpu().numpy(), ob.terminated)
+        assert np.array_equal(eng.get_scores(), ob.score)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)
+    # masked reset consumes exactly two spawns of the selected boards' generators
+    mask = (np.arange(n) % 5 == 0).astype(np.uint8)
+    before = eng.get_numpy_rng().T.copy()
+    eng.reset(mask=torch.as_tensor(mask))
+    after = eng.get_numpy_rng().T
+    assert np.array_equal(after[mask == 0], before[mask == 0]) and not np.array_equal(after[mask == 1], before[mask == 1])
+    assert ((eng.get_boards()[mask == 1] != 0).sum(axis=(1, 2)) == 2).all()
+
+
+def test_seeding_helpers_round_trip():
+    from gym2048_amd.seeding import pcg64_planes, planes_to_generators
+    planes = pcg64_planes([3, 4, 2 ** 35])
+    gens = planes_to_generators(planes)
+    for s, g in zip([3, 4, 2 ** 35], gens):
+        want = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+        assert g.random() == want.random() and g.integers(0, 100) == want.integers(0, 100)
