@@ -102,6 +102,32 @@ __global__ void __launch_bounds__(256) kern_nt(const Args p)
     }
     if (__ballot(r.terminated) && r.terminated) p.last_score[i] = r.terminal_score;
 }
+// phase-shifted start: blocks of one "kind" sleep before issuing their loads, so that on every SIMD half
+// of the resident waves compute while the other half loads/stores
+template <int SHIFT, int DELAY>
+__global__ void __launch_bounds__(256) kern_phase(const Args p)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    if ((blockIdx.x >> SHIFT) & 1u) {
+#pragma unroll 1
+        for (int d = 0; d < DELAY; ++d) __builtin_amdgcn_s_sleep(8); // ~512 cycles per iteration
+    }
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.boards) + i);
+    int32_t score = __builtin_nontemporal_load(p.score + i);
+    const uint32_t a = __builtin_nontemporal_load(p.actions + i);
+    Board bd{{v.x, v.y, v.z, v.w}};
+    const Words w = philox4x32_10(p.t_lo, 0u, i, 0u, p.seed_lo, p.seed_hi);
+    const StepResult r = step_env(bd, score, a & 3u, w, 0.0f, 0u, true);
+    const u32x4 o = {bd.r[0], bd.r[1], bd.r[2], bd.r[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(p.boards) + i);
+    __builtin_nontemporal_store(score, p.score + i);
+    __builtin_nontemporal_store(r.reward, p.reward + i);
+    __builtin_nontemporal_store((uint8_t)r.terminated, p.terminated + i);
+    if (__ballot(r.terminated) && r.terminated) p.last_score[i] = r.terminal_score;
+}
+template <int SHIFT, int DELAY> void launch_phase(const Args &a, uint32_t blocks) { hipLaunchKernelGGL((kern_phase<SHIFT, DELAY>), dim3(blocks), dim3(256), 0, 0, a); }
+
 // two boards per lane (i and i + n/2), all nt, both loads up front
 template <int NB>
 __global__ void __launch_bounds__(256) kern_nt_multi(const Args p)
@@ -259,6 +285,15 @@ int main(int argc, char **argv)
         {"v14 plain loads, nt stores", launch_nt<0, 1>, full},
         {"v14 nt loads, nt stores", launch_nt<1, 1>, full},
         {"v14 nt loads, nt stores, NO score array", launch_nt<1, 1, 0>, full},
+        {"v16 phase shift blk&1, ~0.25us", launch_phase<0, 1>, full},
+        {"v16 phase shift blk&1, ~0.5us", launch_phase<0, 2>, full},
+        {"v16 phase shift blk&1, ~1us", launch_phase<0, 4>, full},
+        {"v16 phase shift blk&1, ~1.5us", launch_phase<0, 6>, full},
+        {"v16 phase shift blk&1, ~2us", launch_phase<0, 8>, full},
+        {"v16 phase shift (blk>>8)&1, ~1us", launch_phase<8, 4>, full},
+        {"v16 phase shift (blk>>8)&1, ~1.5us", launch_phase<8, 6>, full},
+        {"v16 phase shift (blk>>3)&1, ~1us", launch_phase<3, 4>, full},
+        {"v16 phase shift (blk>>3)&1, ~1.5us", launch_phase<3, 6>, full},
         {"v15 nt, 2 boards per lane", launch_nt_multi<2>, full},
         {"v15 nt, 4 boards per lane", launch_nt_multi<4>, full},
         {"v13 block 64", launch_bs<ALL | F_IDX64, 64>, full},
