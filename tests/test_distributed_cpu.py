@@ -41,10 +41,10 @@ def _worker(rank, world, port, n_global, steps, seed, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_global", [4096, 1001])   # equal shards and ragged shards
-def test_two_rank_shards_equal_single_process(tmp_path, n_global):
+@pytest.mark.parametrize("n_global,world", [(4096, 2), (1001, 2), (1003, 4)])   # equal and ragged shards
+def test_sharded_ranks_equal_single_process(tmp_path, n_global, world):
     from oracle import OracleBatch
-    steps, seed, world = 40, 42, 2
+    steps, seed = 40, 42
     mp.spawn(_worker, args=(world, _free_port(), n_global, steps, seed, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "gathered.npz")
     ref = OracleBatch(n_global, seed)
