@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class G2048Error(RuntimeError):
@@ -41,6 +41,7 @@ class Stats(C.Structure):
         ("score_sum", C.c_int64),
         ("max_score", C.c_int32),
         ("max_exp", C.c_uint32),
+        ("highest_hist", C.c_uint32 * 32),
     ]
 
 
@@ -54,7 +55,7 @@ SIGNATURES = {
     "g2048_abi_version": (C.c_int, []),
     "g2048_create": (C.c_int, [_u64, C.c_int, _u64, _u64, C.POINTER(_E)]),
     "g2048_destroy": (C.c_int, [_E]),
-    "g2048_seed": (C.c_int, [_E, _u64]),
+    "g2048_seed": (C.c_int, [_E, _u64, _S]),
     "g2048_get_clock": (C.c_int, [_E, C.POINTER(_u64)]),
     "g2048_set_clock": (C.c_int, [_E, _u64]),
     "g2048_num_boards": (_u64, [_E]),
@@ -75,8 +76,7 @@ SIGNATURES = {
     "g2048_get_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_set_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_last_scores": (C.c_int, [_E, C.c_void_p, _S]),
-    "g2048_boards_ptr": (C.c_void_p, [_E]),
-    "g2048_scores_ptr": (C.c_void_p, [_E]),
+    "g2048_records_ptr": (C.c_void_p, [_E]),
     "g2048_last_score_ptr": (C.c_void_p, [_E]),
     "g2048_episode_stats": (C.c_int, [_E, C.POINTER(Stats), _S]),
     "g2048_set_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),
@@ -85,8 +85,15 @@ SIGNATURES = {
     "g2048_augment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _u64, C.c_void_p, C.c_void_p, C.c_void_p, _S]),
     "g2048_state_bytes": (_u64, [_E]),
     "g2048_get_state": (C.c_int, [_E, C.c_void_p, _S]),
-    "g2048_set_state": (C.c_int, [_E, C.c_void_p, _S]),
+    "g2048_set_state": (C.c_int, [_E, C.c_void_p, _u64, _S]),
+    "g2048_canonicalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _u64, C.c_void_p, _S]),
+    "g2048_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "g2048_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "g2048_comm_destroy": (C.c_int, [C.c_void_p]),
+    "g2048_allgather_returns": (C.c_int, [_E, C.c_void_p, C.c_void_p, _S]),
+    "g2048_allgather_returns_local": (C.c_int, [C.POINTER(_E), C.c_int, C.POINTER(C.c_void_p), C.POINTER(_S)]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -118,7 +118,7 @@ class Batched2048:
             # hashed and seeded on the device (g2048_pcg64.h), identical to numpy's own result
             check(self._lib.g2048_seed_numpy(self._h, int(seed) & (2**64 - 1), self._stream()))
         else:
-            check(self._lib.g2048_seed(self._h, int(seed) & (2**64 - 1)))
+            check(self._lib.g2048_seed(self._h, int(seed) & (2**64 - 1), self._stream()))
 
     def set_numpy_rng(self, planes):
         """Install per-board numpy PCG64 states (uint64 ``[5, n]``, see ``seeding.pcg64_planes``) and
@@ -157,7 +157,6 @@ class Batched2048:
             mptr = C.c_void_p(mask.data_ptr())
         check(self._lib.g2048_reset(self._h, int(bool(new_transaction)), int(first_slot), mptr, self._stream()))
         self._fresh = False
-        return self.boards()
 
     def _as_device(self, x, dtype=None):
         if not isinstance(x, torch.Tensor):
@@ -211,9 +210,14 @@ class Batched2048:
             if act.dim() != 2 or act.shape[1] != self.n_envs:
                 raise ValueError("actions must be [k, n_envs]")
             k = act.shape[0]
-        for t in (reward, terminated, illegal, highest):
-            if t is not None and (t.shape != (k, self.n_envs) or not t.is_contiguous() or t.device != self.device):
+        for t, dt in ((reward, torch.float32), (terminated, torch.uint8), (illegal, torch.uint8), (highest, torch.uint8)):
+            if t is None:
+                continue
+            if t.shape != (k, self.n_envs) or not t.is_contiguous() or t.device != self.device:
                 raise ValueError("rollout buffers must be contiguous [k, n_envs] tensors on the engine's device")
+            if t.dtype != dt and not (dt == torch.uint8 and t.dtype == torch.bool):
+                raise TypeError(f"rollout buffer has dtype {t.dtype}; the kernels write {dt} "
+                                "(reward float32; terminated / illegal / highest uint8 or bool)")
         io = self._io(act, reward, terminated, illegal, highest, None)
         fn = self._lib.g2048_rollout_fused if fused else self._lib.g2048_rollout
         check(fn(self._h, k, C.byref(io), self.n_envs, int(auto_reset), self._stream()))
@@ -231,24 +235,41 @@ class Batched2048:
             t_first = self.clock + 1
         if out is None:
             out = torch.empty((k_steps, self.n_envs), dtype=torch.uint8, device=self.device)
+        if (out.dtype != torch.uint8 or tuple(out.shape) != (k_steps, self.n_envs) or not out.is_contiguous()
+                or out.device != self.device):
+            raise ValueError(f"out must be a contiguous uint8 [{k_steps}, {self.n_envs}] tensor on {self.device}")
         check(self._lib.g2048_fill_random_actions(self._h, int(t_first), int(k_steps), out.data_ptr(), self._stream()))
         return out
 
     # ------------------------------------------------------------------ observations
-    def boards(self) -> torch.Tensor:
-        """Zero-copy ``uint8 [n, 4, 4]`` view of the engine's board state (exponents)."""
+    def records(self) -> torch.Tensor:
+        """Zero-copy ``uint8 [n, 16]`` view of the engine's board RECORDS (include/g2048.h): cell j of a
+        board is ``byte j & 0x1f``; the spare bits of bytes 8..15 carry the packed score deficit."""
         if self._boards_view is None:
-            ptr = self._lib.g2048_boards_ptr(self._h)
-            view = torch.as_tensor(_DeviceView(ptr, (self.n_envs, 4, 4), "|u1"), device=self.device)
+            ptr = self._lib.g2048_records_ptr(self._h)
+            view = torch.as_tensor(_DeviceView(ptr, (self.n_envs, 16), "|u1"), device=self.device)
             if view.data_ptr() != ptr:
-                raise G2048Error("torch did not alias the engine's board memory")
+                raise G2048Error("torch did not alias the engine's record memory")
             self._boards_view = view
         return self._boards_view
 
-    def scores(self) -> torch.Tensor:
-        """Zero-copy ``int32 [n]`` view of the episodic merge scores (game2048_env.py:86)."""
-        ptr = self._lib.g2048_scores_ptr(self._h)
-        return torch.as_tensor(_DeviceView(ptr, (self.n_envs,), "<i4"), device=self.device)
+    def boards(self, out=None) -> torch.Tensor:
+        """``uint8 [n, 4, 4]`` exponents on the device (a snapshot written by a kernel into ``out``)."""
+        if out is None:
+            out = torch.empty((self.n_envs, 4, 4), dtype=torch.uint8, device=self.device)
+        if out.dtype != torch.uint8 or out.numel() != self.n_envs * 16 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous uint8 tensor of n*16 elements on the engine's device")
+        check(self._lib.g2048_get_boards(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def scores(self, out=None) -> torch.Tensor:
+        """``int32 [n]`` episodic merge scores (game2048_env.py:86) on the device (computed from the records)."""
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        if out.dtype != torch.int32 or tuple(out.shape) != (self.n_envs,) or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous int32 [n] tensor on the engine's device")
+        check(self._lib.g2048_get_scores(self._h, out.data_ptr(), self._stream()))
+        return out
 
     def last_scores(self) -> torch.Tensor:
         """Zero-copy ``int32 [n]``: final score of each board's most recently finished episode."""
@@ -281,7 +302,11 @@ class Batched2048:
         if isinstance(boards, torch.Tensor):
             b = boards.to(torch.uint8).contiguous()
             assert b.numel() == self.n_envs * 16
+            if b.device.type == "cuda" and b.device != self.device:
+                b = b.to(self.device)
             check(self._lib.g2048_set_boards(self._h, b.data_ptr(), self._stream()))
+            if b.device.type == "cuda":
+                b.record_stream(torch.cuda.current_stream(self.device))
         else:
             b = np.ascontiguousarray(boards, dtype=np.uint8)
             assert b.size == self.n_envs * 16
@@ -293,7 +318,14 @@ class Batched2048:
         return buf
 
     def set_scores(self, scores):
-        s = np.ascontiguousarray(scores, dtype=np.int32)
+        """self.score for every board (int32 in 0 .. 2^24-1), host array or device tensor."""
+        if isinstance(scores, torch.Tensor) and scores.device.type == "cuda":
+            s = scores.to(self.device, torch.int32).contiguous()
+            assert s.numel() == self.n_envs
+            check(self._lib.g2048_set_scores(self._h, s.data_ptr(), self._stream()))
+            s.record_stream(torch.cuda.current_stream(self.device))
+            return
+        s = np.ascontiguousarray(scores.cpu().numpy() if isinstance(scores, torch.Tensor) else scores, dtype=np.int32)
         assert s.size == self.n_envs
         check(self._lib.g2048_set_scores(self._h, s.ctypes.data, self._stream()))
 
@@ -309,7 +341,8 @@ class Batched2048:
         check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
         return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, score_sum=st.score_sum,
                     max_score=st.max_score, max_exp=st.max_exp,
-                    mean_score=(st.score_sum / st.episodes) if st.episodes else 0.0)
+                    mean_score=(st.score_sum / st.episodes) if st.episodes else 0.0,
+                    highest_hist=[int(x) for x in st.highest_hist])
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:
@@ -323,7 +356,7 @@ class Batched2048:
         base = self._lib.g2048_state_bytes(self._h) - (40 * self.n_envs if self.rng_mode == "numpy" else 0)
         if blob.size not in (base, base + 40 * self.n_envs):
             raise ValueError("state blob size does not match this engine")
-        check(self._lib.g2048_set_state(self._h, blob.ctypes.data, self._stream()))
+        check(self._lib.g2048_set_state(self._h, blob.ctypes.data, blob.size, self._stream()))
         self._fresh = bool(state.get("fresh", False))
         self.rng_mode = state.get("rng_mode", "philox")
 

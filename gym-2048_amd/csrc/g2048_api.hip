@@ -4,9 +4,12 @@
 
 #include "g2048_kernels.h"
 
+#include <rccl/rccl.h> // declarations only: librccl is dlopen()ed by the first g2048_comm_* call
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 
 namespace {
@@ -29,7 +32,7 @@ int fail(int code, const char *fmt, ...)
             return fail(G2048_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(err_));                       \
     } while (0)
 
-constexpr uint64_t kStateMagic = 0x3834303247ull; // "G2048"
+constexpr uint64_t kStateMagic = 0x3276383430324700ull; // "\0G2048v2": records carry the score (layout 2)
 
 } // namespace
 
@@ -46,6 +49,7 @@ struct g2048_engine {
     size_t slab_bytes = 0;
     g2048::DeviceState st{};
     g2048::StatsOut *stats_dev = nullptr;
+    void *scratch = nullptr; // staging for host-side get/set of boards and scores (16 B per board), lazily
 };
 
 namespace {
@@ -111,7 +115,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 6; }
+int g2048_abi_version(void) { return 7; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -141,17 +145,17 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
 
     const size_t n = n_boards;
     const size_t off_boards = 0;
-    const size_t off_score = off_boards + align_up(n * 16);
-    const size_t off_last_score = off_score + align_up(n * 4);
+    const size_t off_last_score = off_boards + align_up(n * 16);
     const size_t off_wave_stats = off_last_score + align_up(n * 4);
-    // one slot per wavefront of the launch grid (whole 256-lane blocks)
-    const size_t n_slots = ((n + 255) / 256) * 4;
+    // one slot per 64 boards, rounded up to whole 1024-lane blocks
+    const size_t n_slots = ((n + 1023) / 1024) * 16;
     const size_t off_stats = off_wave_stats + align_up(n_slots * sizeof(g2048::WaveStats));
     e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
     err = hipMalloc(&e->slab, e->slab_bytes);
     if (err != hipSuccess) {
+        const size_t wanted = e->slab_bytes;
         delete e;
-        return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", e->slab_bytes, hipGetErrorString(err));
+        return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", wanted, hipGetErrorString(err));
     }
     err = hipMemset(e->slab, 0, e->slab_bytes);
     if (err != hipSuccess) {
@@ -161,7 +165,6 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     }
     char *base = static_cast<char *>(e->slab);
     e->st.boards = reinterpret_cast<uint4 *>(base + off_boards);
-    e->st.score = reinterpret_cast<int32_t *>(base + off_score);
     e->st.last_score = reinterpret_cast<int32_t *>(base + off_last_score);
     e->st.wave_stats = reinterpret_cast<g2048::WaveStats *>(base + off_wave_stats);
     e->stats_dev = reinterpret_cast<g2048::StatsOut *>(base + off_stats);
@@ -178,6 +181,8 @@ int g2048_destroy(g2048_engine *e)
         (void)hipSetDevice(e->device);
         if (e->st.rng)
             (void)hipFree(e->st.rng);
+        if (e->scratch)
+            (void)hipFree(e->scratch);
         err = hipFree(e->slab);
     }
     delete e;
@@ -186,17 +191,17 @@ int g2048_destroy(g2048_engine *e)
     return G2048_OK;
 }
 
-int g2048_seed(g2048_engine *e, uint64_t seed)
+int g2048_seed(g2048_engine *e, uint64_t seed, void *stream)
 {
     if (!e)
         return fail(G2048_ERR_INVALID, "engine is NULL");
     e->seed = seed;
     e->t = 0;
     e->fresh = 1;
-    // episode statistics restart with the stream
+    // episode statistics restart with the stream: cleared by a kernel ON THE CALLER'S STREAM, so the
+    // clear is ordered against step kernels already enqueued there
     G2048_HIP(hipSetDevice(e->device));
-    G2048_HIP(hipMemset(e->st.last_score, 0, e->n * 4));
-    G2048_HIP(hipMemset(e->st.wave_stats, 0, ((e->n + 255) / 256) * 4 * sizeof(g2048::WaveStats)));
+    G2048_HIP(g2048::launch_clear_stats(e->st, static_cast<uint32_t>(e->n), static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
 
@@ -422,24 +427,114 @@ static int copy_in(g2048_engine *e, void *dst, const void *src, size_t bytes, vo
     return G2048_OK;
 }
 
-int g2048_get_boards(const g2048_engine *e, uint8_t *buf, void *stream)
+// Is p device-accessible memory of this process (hipMalloc / torch tensor)?  Plain host memory is not
+// known to the runtime and makes hipPointerGetAttributes fail.
+static bool is_device_ptr(const void *p)
 {
-    return copy_out(e, buf, e ? e->st.boards : nullptr, e ? e->n * 16 : 0, stream);
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // clear the sticky error of the failed query
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static int ensure_scratch(g2048_engine *e)
+{
+    if (e->scratch)
+        return G2048_OK;
+    hipError_t err = hipMalloc(&e->scratch, e->n * 16);
+    if (err != hipSuccess) {
+        e->scratch = nullptr;
+        return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) for the host staging buffer failed: %s", (size_t)(e->n * 16),
+                    hipGetErrorString(err));
+    }
+    return G2048_OK;
+}
+
+// The engine keeps RECORDS (cells + packed score deficit); the plain views are produced / consumed by
+// small kernels, through the staging buffer when the caller's buffer is host memory.
+int g2048_get_boards(const g2048_engine *ce, uint8_t *buf, void *stream)
+{
+    g2048_engine *e = const_cast<g2048_engine *>(ce);
+    if (!e || !buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n = static_cast<uint32_t>(e->n);
+    if (is_device_ptr(buf)) {
+        G2048_HIP(g2048::launch_export_boards(e->st.boards, n, reinterpret_cast<uint4 *>(buf), s));
+        return G2048_OK; // device destination: ready in stream order
+    }
+    if (int rc = ensure_scratch(e))
+        return rc;
+    G2048_HIP(g2048::launch_export_boards(e->st.boards, n, static_cast<uint4 *>(e->scratch), s));
+    return copy_out(e, buf, e->scratch, e->n * 16, stream);
 }
 
 int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream)
 {
-    return copy_in(e, e ? e->st.boards : nullptr, buf, e ? e->n * 16 : 0, stream);
+    if (!e || !buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n = static_cast<uint32_t>(e->n);
+    const uint4 *src = reinterpret_cast<const uint4 *>(buf);
+    if (!is_device_ptr(buf)) {
+        if (int rc = ensure_scratch(e))
+            return rc;
+        if (int rc = copy_in(e, e->scratch, buf, e->n * 16, stream))
+            return rc;
+        src = static_cast<const uint4 *>(e->scratch);
+    } else if (reinterpret_cast<uintptr_t>(buf) & 15u) {
+        return fail(G2048_ERR_INVALID, "device board buffers must be 16-byte aligned");
+    }
+    G2048_HIP(g2048::launch_import_boards(e->st.boards, n, src, s));
+    if (src == e->scratch) // the staging buffer must be free again when this returns
+        G2048_HIP(hipStreamSynchronize(s));
+    return G2048_OK;
 }
 
-int g2048_get_scores(const g2048_engine *e, int32_t *buf, void *stream)
+int g2048_get_scores(const g2048_engine *ce, int32_t *buf, void *stream)
 {
-    return copy_out(e, buf, e ? e->st.score : nullptr, e ? e->n * 4 : 0, stream);
+    g2048_engine *e = const_cast<g2048_engine *>(ce);
+    if (!e || !buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n = static_cast<uint32_t>(e->n);
+    if (is_device_ptr(buf)) {
+        G2048_HIP(g2048::launch_export_scores(e->st.boards, n, buf, s));
+        return G2048_OK; // device destination: ready in stream order
+    }
+    if (int rc = ensure_scratch(e))
+        return rc;
+    G2048_HIP(g2048::launch_export_scores(e->st.boards, n, static_cast<int32_t *>(e->scratch), s));
+    return copy_out(e, buf, e->scratch, e->n * 4, stream);
 }
 
 int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
 {
-    return copy_in(e, e ? e->st.score : nullptr, buf, e ? e->n * 4 : 0, stream);
+    if (!e || !buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n = static_cast<uint32_t>(e->n);
+    const int32_t *src = buf;
+    if (!is_device_ptr(buf)) {
+        for (uint64_t i = 0; i < e->n; ++i)
+            if (buf[i] < 0 || buf[i] > 0x00ffffff)
+                return fail(G2048_ERR_INVALID, "score %d of board %llu is outside 0 .. 2^24-1", buf[i], (unsigned long long)i);
+        if (int rc = ensure_scratch(e))
+            return rc;
+        if (int rc = copy_in(e, e->scratch, buf, e->n * 4, stream))
+            return rc;
+        src = static_cast<const int32_t *>(e->scratch);
+    }
+    G2048_HIP(g2048::launch_import_scores(e->st.boards, n, src, s));
+    if (src == e->scratch)
+        G2048_HIP(hipStreamSynchronize(s));
+    return G2048_OK;
 }
 
 int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream)
@@ -447,8 +542,7 @@ int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream)
     return copy_out(e, buf, e ? e->st.last_score : nullptr, e ? e->n * 4 : 0, stream);
 }
 
-void *g2048_boards_ptr(const g2048_engine *e) { return e ? e->st.boards : nullptr; }
-void *g2048_scores_ptr(const g2048_engine *e) { return e ? e->st.score : nullptr; }
+void *g2048_records_ptr(const g2048_engine *e) { return e ? e->st.boards : nullptr; }
 void *g2048_last_score_ptr(const g2048_engine *e) { return e ? e->st.last_score : nullptr; }
 
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
@@ -466,6 +560,8 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     out->score_sum = static_cast<int64_t>(h.score_sum);
     out->max_score = h.max_score;
     out->max_exp = h.max_exp;
+    for (int k = 0; k < 32; ++k)
+        out->highest_hist[k] = h.highest_hist[k];
     return G2048_OK;
 }
 
@@ -492,7 +588,7 @@ int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
 
 int g2048_seed_numpy(g2048_engine *e, uint64_t base_seed, void *stream)
 {
-    if (int rc = g2048_seed(e, base_seed))
+    if (int rc = g2048_seed(e, base_seed, stream))
         return rc;
     if (!e->st.rng) {
         void *p = nullptr;
@@ -546,15 +642,24 @@ int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream)
     return G2048_OK;
 }
 
-int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream)
+int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, void *stream)
 {
     if (!e || !host_buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
+    if (blob_bytes < sizeof(StateHeader))
+        return fail(G2048_ERR_INVALID, "state blob is too short (%llu bytes)", (unsigned long long)blob_bytes);
     StateHeader h;
     std::memcpy(&h, host_buf, sizeof h);
     if (h.magic != kStateMagic || h.n != e->n)
         return fail(G2048_ERR_INVALID, "state blob does not match this engine (magic %llx, n %llu vs %llu)",
                     (unsigned long long)h.magic, (unsigned long long)h.n, (unsigned long long)e->n);
+    const uint64_t want = sizeof(StateHeader) + e->slab_bytes + (h.reserved ? e->n * 40 : 0);
+    if (blob_bytes != want)
+        return fail(G2048_ERR_INVALID, "state blob is %llu bytes, this engine's state is %llu",
+                    (unsigned long long)blob_bytes, (unsigned long long)want);
+    if (h.max_exp > 31u || h.board_offset + h.n > 0x100000000ull)
+        return fail(G2048_ERR_INVALID, "state blob header is corrupt (max_exp %u, board_offset %llu)", h.max_exp,
+                    (unsigned long long)h.board_offset);
     e->seed = h.seed;
     e->board_offset = h.board_offset;
     e->t = h.t;
@@ -567,6 +672,197 @@ int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream)
     if (h.reserved) // the blob carries numpy-RNG planes
         return g2048_set_numpy_rng(e, reinterpret_cast<const uint64_t *>(body + e->slab_bytes), stream);
     return g2048_set_numpy_rng(e, nullptr, stream);
+}
+
+int g2048_canonicalize(uint8_t *boards, uint8_t *next_boards, uint8_t *actions, uint64_t n, uint8_t *symmetry_out,
+                       void *stream)
+{
+    if (!boards)
+        return fail(G2048_ERR_INVALID, "boards is NULL");
+    if (n > 0xffffff00ull)
+        return fail(G2048_ERR_INVALID, "n too large");
+    if ((reinterpret_cast<uintptr_t>(boards) | reinterpret_cast<uintptr_t>(next_boards)) & 15u)
+        return fail(G2048_ERR_INVALID, "board buffers must be 16-byte aligned");
+    G2048_HIP(g2048::launch_canonicalize(reinterpret_cast<uint4 *>(boards), reinterpret_cast<uint4 *>(next_boards), actions,
+                                         static_cast<uint32_t>(n), symmetry_out, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+// ------------------------------------------------------------------------------- collective
+// The path's only exchange step: the all-gather of episodic returns (last_score) once per rollout.
+// RCCL is bound lazily (dlopen) so that the library loads, and everything else works, on a box without
+// RCCL or without a GPU; a process that never calls g2048_comm_* never touches it.
+} // extern "C"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle)
+        return G2048_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (h)
+            break;
+    }
+    if (!h)
+        return fail(G2048_ERR_HIP, "cannot load RCCL (librccl.so): %s", dlerror());
+    Rccl r;
+    r.handle = h;
+#define G2048_SYM(field, name)                                                                                 \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name));                                             \
+    if (!r.field)                                                                                              \
+        return fail(G2048_ERR_HIP, "RCCL has no symbol %s", name);
+    G2048_SYM(GetUniqueId, "ncclGetUniqueId")
+    G2048_SYM(CommInitRank, "ncclCommInitRank")
+    G2048_SYM(CommInitAll, "ncclCommInitAll")
+    G2048_SYM(CommDestroy, "ncclCommDestroy")
+    G2048_SYM(AllGather, "ncclAllGather")
+    G2048_SYM(GroupStart, "ncclGroupStart")
+    G2048_SYM(GroupEnd, "ncclGroupEnd")
+    G2048_SYM(GetErrorString, "ncclGetErrorString")
+#undef G2048_SYM
+    g_rccl = r;
+    return G2048_OK;
+}
+
+#define G2048_NCCL(call)                                                                                       \
+    do {                                                                                                       \
+        ncclResult_t r_ = (call);                                                                              \
+        if (r_ != ncclSuccess)                                                                                 \
+            return fail(G2048_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r_));                      \
+    } while (0)
+
+} // namespace
+
+struct g2048_comm {
+    ncclComm_t comm = nullptr;
+    int world = 0, rank = 0, device = 0;
+};
+
+extern "C" {
+
+int g2048_comm_unique_id(uint8_t id[G2048_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) <= G2048_COMM_ID_BYTES, "ncclUniqueId does not fit G2048_COMM_ID_BYTES");
+    if (!id)
+        return fail(G2048_ERR_INVALID, "id is NULL");
+    if (int rc = load_rccl())
+        return rc;
+    ncclUniqueId u;
+    G2048_NCCL(g_rccl.GetUniqueId(&u));
+    std::memset(id, 0, G2048_COMM_ID_BYTES);
+    std::memcpy(id, &u, sizeof u);
+    return G2048_OK;
+}
+
+int g2048_comm_create(int world, int rank, const uint8_t id[G2048_COMM_ID_BYTES], int device, g2048_comm **out)
+{
+    if (!out || !id)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world)
+        return fail(G2048_ERR_INVALID, "rank %d / world %d out of range", rank, world);
+    if (int rc = load_rccl())
+        return rc;
+    G2048_HIP(hipSetDevice(device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    g2048_comm *c = new (std::nothrow) g2048_comm;
+    if (!c)
+        return fail(G2048_ERR_NOMEM, "out of host memory");
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(G2048_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+    }
+    *out = c;
+    return G2048_OK;
+}
+
+int g2048_comm_destroy(g2048_comm *c)
+{
+    if (!c)
+        return G2048_OK;
+    ncclResult_t r = c->comm ? g_rccl.CommDestroy(c->comm) : ncclSuccess;
+    delete c;
+    if (r != ncclSuccess)
+        return fail(G2048_ERR_HIP, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
+    return G2048_OK;
+}
+
+int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, void *stream)
+{
+    if (!e || !c || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    if (c->device != e->device)
+        return fail(G2048_ERR_INVALID, "communicator is on device %d, engine on device %d", c->device, e->device);
+    G2048_HIP(hipSetDevice(e->device));
+    // equal shards: rank r's n returns land at out[r * n]
+    G2048_NCCL(g_rccl.AllGather(e->st.last_score, out, e->n, ncclInt32, c->comm, static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, int32_t *const *outs, void *const *streams)
+{
+    if (!engines || !outs || n_engines < 1)
+        return fail(G2048_ERR_INVALID, "bad argument");
+    if (n_engines > 64)
+        return fail(G2048_ERR_INVALID, "at most 64 engines");
+    for (int r = 0; r < n_engines; ++r) {
+        if (!engines[r] || !outs[r])
+            return fail(G2048_ERR_INVALID, "engine or output %d is NULL", r);
+        if (engines[r]->n != engines[0]->n)
+            return fail(G2048_ERR_INVALID, "engines must hold equal shards (engine %d has %llu boards, engine 0 %llu)", r,
+                        (unsigned long long)engines[r]->n, (unsigned long long)engines[0]->n);
+    }
+    if (int rc = load_rccl())
+        return rc;
+    int devs[64];
+    ncclComm_t comms[64];
+    for (int r = 0; r < n_engines; ++r)
+        devs[r] = engines[r]->device;
+    G2048_NCCL(g_rccl.CommInitAll(comms, n_engines, devs)); // single process, one communicator per device
+    int rc = G2048_OK;
+    ncclResult_t res = g_rccl.GroupStart();
+    for (int r = 0; r < n_engines && res == ncclSuccess; ++r) {
+        if (hipSetDevice(devs[r]) != hipSuccess) {
+            res = ncclUnhandledCudaError;
+            break;
+        }
+        res = g_rccl.AllGather(engines[r]->st.last_score, outs[r], engines[r]->n, ncclInt32, comms[r],
+                               static_cast<hipStream_t>(streams ? streams[r] : nullptr));
+    }
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (res == ncclSuccess)
+        res = end;
+    for (int r = 0; r < n_engines; ++r) {
+        if (hipSetDevice(devs[r]) == hipSuccess)
+            (void)hipStreamSynchronize(static_cast<hipStream_t>(streams ? streams[r] : nullptr));
+        (void)g_rccl.CommDestroy(comms[r]);
+    }
+    if (res != ncclSuccess)
+        rc = fail(G2048_ERR_HIP, "RCCL all-gather failed: %s", g_rccl.GetErrorString(res));
+    return rc;
 }
 
 } // extern "C"

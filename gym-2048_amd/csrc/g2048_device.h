@@ -296,6 +296,132 @@ G2048_DEV bool is_end(const Board &bd, uint32_t max_exp)
     return end;
 }
 
+// ------------------------------------------------------------ direction by per-lane selectors
+// The same move() without the select network: v_perm_b32 takes its byte selector from a VGPR, so
+// a two-stage perm network whose SELECTORS depend on the lane's action maps the board straight to
+// the shift-order registers A..D (reversal included) and back -- 16 v_perm, no v_bitop3 selects.
+//   stage 1: x0 = perm(r1, r0, sa)  x1 = perm(r1, r0, sb)  x2 = perm(r3, r2, sa)  x3 = perm(r3, r2, sb)
+//   stage 2: A  = perm(x2, x0, ta)  C  = perm(x2, x0, tc)  B  = perm(x3, x1, ta)  D  = perm(x3, x1, tc)
+// Stage 2 is an involution (the way back uses ta, tc again); stage 1 is undone with va, vb.
+// The table (one 32-byte row per action, game2048_env.py:196: 0 up, 1 right, 2 down, 3 left) is
+// derived and checked by tests/test_device_math_host.py::test_move_lut.  The kernels keep it in LDS
+// and fetch a lane's row with two ds_read (no VALU); the host check indexes the array directly.
+struct MoveSel {
+    uint32_t sa, sb, ta, tc, va, vb;
+};
+
+#define G2048_MOVE_LUT_WORDS                                                                        \
+    0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0u, 0u, /* up */     \
+    0x05010703u, 0x04000602u, 0x05040100u, 0x07060302u, 0x00040206u, 0x01050307u, 0u, 0u, /* right */  \
+    0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0u, 0u, /* down */   \
+    0x06020400u, 0x07030501u, 0x05040100u, 0x07060302u, 0x06020400u, 0x07030501u, 0u, 0u  /* left */
+
+// game2048_env.py:194-241 with the lane's selector row.  Returns true when the board changed.
+G2048_DEV bool move_sel(Board &bd, const MoveSel &s, uint32_t &score)
+{
+    const uint32_t x0 = g2048_perm(bd.r[1], bd.r[0], s.sa), x1 = g2048_perm(bd.r[1], bd.r[0], s.sb);
+    const uint32_t x2 = g2048_perm(bd.r[3], bd.r[2], s.sa), x3 = g2048_perm(bd.r[3], bd.r[2], s.sb);
+    uint32_t a = g2048_perm(x2, x0, s.ta), c = g2048_perm(x2, x0, s.tc);
+    uint32_t b = g2048_perm(x3, x1, s.ta), d = g2048_perm(x3, x1, s.tc);
+    const uint32_t a0 = a, b0 = b, c0 = c, d0 = d;
+    score = shift4(a, b, c, d);
+    const bool changed = ((a ^ a0) | (b ^ b0) | (c ^ c0) | (d ^ d0)) != 0; // :222,234,238
+    const uint32_t y0 = g2048_perm(c, a, s.ta), y2 = g2048_perm(c, a, s.tc);
+    const uint32_t y1 = g2048_perm(d, b, s.ta), y3 = g2048_perm(d, b, s.tc);
+    bd.r[0] = g2048_perm(y1, y0, s.va);
+    bd.r[1] = g2048_perm(y1, y0, s.vb);
+    bd.r[2] = g2048_perm(y3, y2, s.va);
+    bd.r[3] = g2048_perm(y3, y2, s.vb);
+    return changed;
+}
+
+// ------------------------------------------------------------------- the 16-byte board RECORD
+// What the engine keeps per board in HBM is ONE 16-byte record: bits [4:0] of byte j = exponent of
+// cell j (0..31), and the 24-bit SCORE DEFICIT d in the three spare bits [7:5] of bytes 8..15
+// (registers r[2], r[3]; bit k of d lives in bit 5 + k % 3 of byte 8 + k / 3).
+//   d = (potential(board) - score) mod 2^24,   potential = sum over tiles of (e - 1) * 2^e.
+// Why a deficit and not the score: a merge of two 2^e tiles raises the potential by exactly the 2^(e+1)
+// it scores (game2048_env.py:253-254), a spawned 2 leaves it alone and a spawned 4 raises it by 4
+// without scoring -- so d changes only when a 4 is spawned (d += 4), which in the spread layout is one
+// carry-propagating add; the episodic score self.score (game2048_env.py:46,86,105) is recovered as
+// potential - d where it is needed (episode end, get_scores).  No separate score array: a step reads
+// and writes exactly the 16-byte record.  Scores are exact below 2^24 = 16 777 216 (the largest score
+// a 4x4 game can reach is about 3.9 million).
+constexpr uint32_t kCellBits = 0x1f1f1f1fu, kSpareBits = 0xe0e0e0e0u, kScoreMask = 0x00ffffffu;
+
+G2048_DEV Board record_cells(const Board &raw)
+{
+    return Board{{raw.r[0], raw.r[1], raw.r[2] & kCellBits, raw.r[3] & kCellBits}};
+}
+
+// sum over the 16 cells of (e - 1) * 2^e (0 for an empty cell); cells must be masked (e <= 31)
+G2048_DEV uint32_t potential(const Board &cells)
+{
+    uint32_t hi = 0, lo = 0; // sum e << e, sum 1 << e
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const uint32_t e = (cells.r[i] >> (8 * l)) & 0xffu;
+            hi += e << (e & 31u);
+            lo += 1u << (e & 31u);
+        }
+    }
+    return hi - lo + count_empty(cells); // an empty cell contributed 0 - 1
+}
+
+// 12 spare bits of one register -> 12 contiguous bits
+G2048_DEV uint32_t gather12(uint32_t r)
+{
+    uint32_t y = (r >> 5) & 0x07070707u;
+    y = (y | (y >> 5)) & 0x003f003fu;
+    return (y | (y >> 10)) & 0xfffu;
+}
+
+// 12 contiguous bits -> the spare bits of one register
+G2048_DEV uint32_t scatter12(uint32_t v)
+{
+    uint32_t y = (v | (v << 10)) & 0x003f003fu;
+    y = (y | (y << 5)) & 0x07070707u;
+    return y << 5;
+}
+
+G2048_DEV uint32_t record_deficit(const Board &raw) { return gather12(raw.r[2]) | (gather12(raw.r[3]) << 12); }
+
+G2048_DEV uint32_t record_score(const Board &raw)
+{
+    return (potential(record_cells(raw)) - record_deficit(raw)) & kScoreMask;
+}
+
+G2048_DEV Board make_record(const Board &cells, uint32_t score)
+{
+    const uint32_t d = (potential(cells) - score) & kScoreMask;
+    return Board{{cells.r[0], cells.r[1], cells.r[2] | scatter12(d & 0xfffu), cells.r[3] | scatter12(d >> 12)}};
+}
+
+// d += inc (inc = 0 or 4, given as the spread value 0 / 0x80 for bit 2 of d) without leaving the
+// spread layout: the cell bits between the deficit bits are filled with ones so that the carry runs
+// through them, then the new cells are put back.
+G2048_DEV void record_update(Board &raw, const Board &cells, uint32_t inc_spread)
+{
+    const uint64_t filled = (static_cast<uint64_t>(raw.r[3] | kCellBits) << 32) | (raw.r[2] | kCellBits);
+    const uint64_t sum = filled + inc_spread;
+    raw.r[0] = cells.r[0];
+    raw.r[1] = cells.r[1];
+    raw.r[2] = bfi(kSpareBits, static_cast<uint32_t>(sum), cells.r[2]);
+    raw.r[3] = bfi(kSpareBits, static_cast<uint32_t>(sum >> 32), cells.r[3]);
+}
+
+// game2048_env.py:102-111 as a record: fresh board, score 0, so d = potential = 4 per spawned 4.
+G2048_DEV Board fresh_record(uint32_t w1, uint32_t w2)
+{
+    Board bd = fresh_board(w1, w2);
+    const uint32_t fours = (((w1 & 0xffffu) <= 58982u) ? 0u : 1u) + (((w2 & 0xffffu) <= 58982u) ? 0u : 1u);
+    // d = 4 -> bit 2 of d = bit 7 of byte 8; d = 8 -> bit 3 of d = bit 5 of byte 9
+    bd.r[2] |= fours == 1u ? 0x80u : (fours == 2u ? 0x2000u : 0u);
+    return bd;
+}
+
 // ------------------------------------------------------------------------------ one env step
 struct StepResult {
     float reward;

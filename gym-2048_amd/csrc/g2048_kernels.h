@@ -7,9 +7,10 @@
 
 namespace g2048 {
 
-// Per-wavefront episode accumulators: the only episode bookkeeping the hot kernel touches besides
-// last_score.  One slot per 64 boards, private to the wave that owns them (plain load-add-store by lane 0), so a step
-// adds no per-board read-modify-write traffic.
+// Episode accumulators: the only episode bookkeeping the step kernels touch besides last_score.
+// One slot per 64 boards.  step_kernel uses the FIRST slot of each thread block (updated once per
+// launch by the block's fixer wave, plain load-add-store by one lane); the fused rollout kernels use
+// the slot of each wavefront.  stats_kernel sums all slots.
 struct alignas(8) WaveStats {
     unsigned int episodes;        // finished episodes
     unsigned int illegal_ends;    // ... of which ended on an illegal move
@@ -20,8 +21,9 @@ struct alignas(8) WaveStats {
 
 // Engine-owned device state (one slab).
 struct DeviceState {
-    uint4 *boards;         // [n]   16 x int8 exponents per board
-    int32_t *score;        // [n]   episodic merge score (game2048_env.py:86)
+    uint4 *boards;         // [n]   16-byte board RECORDS: 16 x 5-bit exponents + the 24-bit score deficit in
+                           //       the spare bits of bytes 8..15 (g2048_device.h "board RECORD"); there is no
+                           //       separate score array -- self.score (game2048_env.py:86) = potential - deficit
     int32_t *last_score;   // [n]   final score of the board's last finished episode (write-only here)
     WaveStats *wave_stats; // one per wavefront of the launch grid
     uint64_t *rng;         // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
@@ -51,6 +53,7 @@ struct StatsOut {
     unsigned long long score_sum;
     int max_score;
     unsigned int max_exp;
+    unsigned int highest_hist[32]; // boards whose highest tile is 2^k right now (game2048_env.py:190-192)
 };
 
 hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s);
@@ -73,5 +76,13 @@ hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dty
 hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const uint8_t *actions, uint32_t n,
                           uint4 *boards_out, uint4 *next_out, uint8_t *actions_out, hipStream_t s);
 hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hipStream_t s);
+// record <-> plain views (cells uint8[n][16], scores int32[n]); device pointers
+hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s);
+hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s);
+hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *scores_out, hipStream_t s);
+hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, hipStream_t s);
+hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s);
+hipError_t launch_canonicalize(uint4 *boards, uint4 *next_boards, uint8_t *actions, uint32_t n, uint8_t *sym_out,
+                               hipStream_t s);
 
 } // namespace g2048

@@ -1,15 +1,19 @@
 // g2048_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched 2048 environment.
 //
-// Mapping: ONE BOARD PER LANE.  A wavefront owns 64 consecutive boards = 1 KiB of board state, read
+// Mapping: ONE BOARD PER LANE.  A wavefront owns 64 consecutive boards = 1 KiB of board records, read
 // and written with one global_load/store_dwordx4 per lane (fully coalesced, 16 B/lane).  The whole
-// step -- slide/merge sweep, score, spawn, done detection, auto-reset -- runs out of VGPRs with
-// byte-parallel integer ops (g2048_device.h); there is no cross-lane traffic, no LDS and no
-// per-board RNG state: the spawn randomness of (transaction t, board b) is one Philox4x32-10 block.
+// step -- slide/merge sweep, score, spawn, done detection -- runs out of VGPRs with byte-parallel
+// integer ops (g2048_device.h); there is no per-board RNG state: the spawn randomness of
+// (transaction t, board b) is one Philox4x32-10 block.
 //
 // HBM bytes per env-step of step_kernel (the roofline figure in DESIGN.md):
 //   algorithmic 38 B = board in 16 + action 1 + board out 16 + reward 4 + terminated 1
-//   plus the episodic score state (4 B in + 4 B out) and, only for boards that terminate, the
-//   episode record.
+// and that is also all a step moves for a board whose episode goes on: the episodic score travels
+// inside the 16-byte record (g2048_device.h "board RECORD").  Boards whose episode ENDS (about 7 % of
+// the steps under a random policy) are handed through LDS to one "fixer" wavefront per thread block,
+// which scores them, writes last_score, installs the fresh board of the auto-reset and updates the
+// block's episode counters -- so the 93 % do not execute the reset / bookkeeping code at all (with one
+// board per lane a wavefront would otherwise run it in 99 % of the launches).
 #include "g2048_kernels.h"
 
 #include "g2048_device.h"
@@ -18,7 +22,8 @@
 
 namespace g2048 {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;     // utility kernels
+constexpr int kStepBlock = 512; // step_kernel: 8 wavefronts share one fixer
 
 // Streaming accesses of the step kernels carry the non-temporal hint (nt=1): every byte is touched
 // exactly once per launch, so it should not displace anything in L2 / Infinity Cache.  Measured on
@@ -36,6 +41,45 @@ __device__ __forceinline__ void store_board_nt(uint4 *boards, uint32_t i, const 
 {
     const u32x4 v = {b.r[0], b.r[1], b.r[2], b.r[3]};
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(boards) + i);
+}
+
+__device__ __forceinline__ Board load_board(const uint4 *boards, uint32_t i)
+{
+    const uint4 v = boards[i];
+    return Board{{v.x, v.y, v.z, v.w}};
+}
+
+__device__ __forceinline__ void store_board(uint4 *boards, uint32_t i, const Board &b)
+{
+    boards[i] = make_uint4(b.r[0], b.r[1], b.r[2], b.r[3]);
+}
+
+// The per-action selector rows of move_sel (g2048_device.h), staged into LDS by the first 32 lanes
+// of a block; a lane then fetches its row with two ds_read_b128 (no VALU work, no bank conflicts:
+// four distinct 32-byte rows).
+__device__ const uint32_t kMoveLut[32] = {G2048_MOVE_LUT_WORDS};
+
+// `x`, but not before `dep` has been computed (pins the s_waitcnt of a load below independent work).
+__device__ __forceinline__ uint32_t use_after(uint32_t x, uint32_t dep)
+{
+    asm volatile("" : "+v"(x) : "v"(dep));
+    return x;
+}
+
+// Two halves so that the global load is issued with the board load and its result is only waited
+// for just before the barrier (after the Philox block).
+__device__ __forceinline__ uint32_t load_move_lut_word() { return threadIdx.x < 32u ? kMoveLut[threadIdx.x] : 0u; }
+
+__device__ __forceinline__ void stage_move_lut(uint4 *s_lut, uint32_t word)
+{
+    if (threadIdx.x < 32u)
+        reinterpret_cast<uint32_t *>(s_lut)[threadIdx.x] = word;
+}
+
+__device__ __forceinline__ MoveSel fetch_move_sel(const uint4 *s_lut, uint32_t action)
+{
+    const uint4 a = s_lut[action * 2u], b = s_lut[action * 2u + 1u];
+    return MoveSel{a.x, a.y, a.z, a.w, b.x, b.y};
 }
 
 template <int ACT>
@@ -79,9 +123,10 @@ __device__ __forceinline__ int wave_max(int v) // non-negative v; result broadca
     return __builtin_amdgcn_readlane(m, 63);
 }
 
-// Episode bookkeeping.  Boards that ended an episode write their final score (and, if asked, their
-// terminal board); the wave's totals are accumulated in lane 63.  The whole block is skipped by a
-// wave-uniform branch when no lane terminated.
+// Episode bookkeeping of the FUSED rollout kernels (the per-step kernel hands finished episodes to
+// its block fixer instead).  Boards that ended an episode write their final score; the wave's totals
+// are accumulated in lane 63.  The whole block is skipped by a wave-uniform branch when no lane
+// terminated.
 struct WaveAcc {
     unsigned int episodes = 0, illegal_ends = 0;
     unsigned long long score_sum = 0; // valid in lane 63 only
@@ -113,10 +158,9 @@ __device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, c
 
 // The wave's slot is private to it (one wave per slot per launch, launches are stream-ordered), so
 // the accumulators are updated with a plain load-add-store by ONE lane (63, where the DPP
-// reductions land).  `old` is loaded at kernel entry, together with the board, so its latency is
-// never exposed.  Requires full wavefronts: the launchers pad the tail wave's bookkeeping by
+// reductions land).  Requires full wavefronts: the launchers pad the tail wave's bookkeeping by
 // running it with all 64 lanes active (boards beyond n are never touched).
-__device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, const WaveStats &old, const WaveAcc &acc)
+__device__ __forceinline__ void flush_wave_stats(WaveStats *slot, const WaveStats &old, const WaveAcc &acc)
 {
     if (acc.episodes == 0 || (threadIdx.x & 63u) != 63u)
         return;
@@ -126,62 +170,199 @@ __device__ __forceinline__ void flush_wave_stats(const StepArgs &p, uint32_t i, 
     ws.score_sum = old.score_sum + acc.score_sum;
     ws.max_score = max(old.max_score, acc.max_score);
     ws.pad = 0;
-    p.st.wave_stats[i >> 6] = ws;
+    *slot = ws;
 }
 
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
-// One board per lane, one pass: load (board 16 B, score 4 B, action) -> ~310 VALU instructions ->
-// store.  The Philox block does not depend on the loaded data, so its ~55 instructions run while
-// the loads are in flight.  Measured alternatives that were NOT faster on MI355X at 2^20 boards
-// (tools/ubench/step_variants.hip): grid-stride loops with the next board prefetched, per-block
-// s_setprio staggering, 32-bit offset addressing.
-template <int ACT>
-__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
+// Per lane: load the 16-byte record + the action -> Philox block (independent of the loads, so it
+// runs while they are in flight) -> move through the lane's selector row (LDS) -> spawn -> done
+// detection -> deficit update -> store record, reward, terminated.  A lane whose episode ended
+// instead appends (terminal record, the two reset spawn words, flags) to its wave's list in LDS.
+// The LAST wavefront of the block to get that far (an LDS arrival counter, no barrier: the other
+// waves retire at once) becomes the block's FIXER: one lane per finished episode computes the
+// final score (potential - deficit), writes last_score, stores the fresh record of the auto-reset
+// (game2048_env.py:102-111) and folds count / illegal ends / score sum / best score into the block's
+// WaveStats slot.
+//
+// LDS per block: selector table 128 B + 2 x 16 B per lane (worst case: every board ends).
+template <int BLOCK>
+struct StepShared {
+    uint4 lut[8];
+    uint4 rec[BLOCK]; // terminal records, wave w's list starts at w * 64
+    uint4 aux[BLOCK]; // {reset spawn word 1, word 2, lane-in-block | do_reset << 30 | illegal << 31, -}
+    uint32_t count[BLOCK / 64];
+    uint32_t arrived;
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void run_fixer(const StepArgs &p, StepShared<BLOCK> &sh)
 {
-    // Lanes past the end stay active (the DPP reductions and the lane-63 flush need whole
-    // wavefronts): they recompute board n-1 and write nothing.
-    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    constexpr int WAVES = BLOCK / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t total = 0;
+    uint32_t pre[WAVES + 1];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        pre[w] = total;
+        total += __builtin_amdgcn_readfirstlane(sh.count[w]); // wave-uniform: keeps the loop scalar
+    }
+    pre[WAVES] = total;
+    if (total == 0)
+        return;
+    WaveStats *slot = p.st.wave_stats + ((blockIdx.x * BLOCK) >> 6);
+    const WaveStats old = *slot; // same address in every lane: one request, in flight during the scoring
+    unsigned int illegal_ends = 0;
+    long long score_sum = 0;
+    int best = 0;
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t j = base + lane;
+        const bool on = j < total;
+        uint32_t wv = 0, start = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            if (j >= pre[w]) {
+                wv = w;
+                start = pre[w];
+            }
+        }
+        const uint32_t e = on ? wv * 64u + (j - start) : 0u;
+        const uint4 rv = sh.rec[e], av = sh.aux[e];
+        const Board term{{rv.x, rv.y, rv.z, rv.w}};
+        const int score = on ? static_cast<int>(record_score(term)) : 0; // :86 self.score at the end
+        const uint32_t i = blockIdx.x * BLOCK + (av.z & 0xffffu);
+        if (on) {
+            // plain (cached) stores: sparse writes that L2 merges into lines
+            p.st.last_score[i] = score;
+            if (av.z & 0x40000000u)
+                store_board(p.st.boards, i, fresh_record(av.x, av.y)); // :102-111
+        }
+        illegal_ends += static_cast<unsigned int>(__popcll(__ballot(on && (av.z >> 31) != 0u)));
+        score_sum += static_cast<long long>(wave_sum(score));
+        if (__ballot(score > max(best, old.max_score)) != 0ull)
+            best = max(best, wave_max(score));
+    }
+    if (lane == 63u) {
+        WaveStats ws;
+        ws.episodes = old.episodes + total;
+        ws.illegal_ends = old.illegal_ends + illegal_ends;
+        ws.score_sum = old.score_sum + static_cast<unsigned long long>(score_sum);
+        ws.max_score = max(old.max_score, best);
+        ws.pad = 0;
+        *slot = ws;
+    }
+}
+
+enum { X_NOFIX = 1, X_OWNERSTORE = 2, X_NOLUT = 4, X_NOBARRIER = 8 }; // experiment switches (tools/ubench/step_v2.hip)
+
+template <int ACT, int BLOCK, int X = 0>
+__global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
+{
+    constexpr int WAVES = BLOCK / 64;
+    static_assert(BLOCK >= 128 && BLOCK % 64 == 0, "step_kernel needs at least two wavefronts per block");
+    __shared__ StepShared<BLOCK> sh;
+    // Lanes past the end stay active (barrier, DPP reductions of the fixer): they recompute board
+    // n-1 and write nothing.
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i_raw = blockIdx.x * BLOCK + tid;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    Board bd = load_board_nt(p.st.boards, i);
-    int32_t score = __builtin_nontemporal_load(p.st.score + i);
-    const WaveStats old_stats = p.st.wave_stats[i_raw >> 6]; // same address in all lanes: one request
+    const Board raw = load_board_nt(p.st.boards, i);
+    const uint32_t lut_word = (X & X_NOLUT) ? 0u : load_move_lut_word();
+    if (tid >= 64u && tid < 64u + WAVES)
+        sh.count[tid - 64u] = 0u;
+    if (tid == 64u + WAVES)
+        sh.arrived = 0u;
 
     const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
     const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
+    if (!(X & X_NOLUT))
+        stage_move_lut(sh.lut, use_after(lut_word, w.w[0])); // the wait for the table word sits after the Philox block
+    if (!(X & X_NOBARRIER))
+        __syncthreads(); // selector table + counters visible; every wave is waiting for its loads anyway
 
-    StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+    Board cells = record_cells(raw);
+    uint32_t gain;
+    bool legal;
+    if (X & X_NOLUT) {
+        legal = move(cells, action, gain);
+    } else {
+        const MoveSel sel = fetch_move_sel(sh.lut, action);
+        legal = move_sel(cells, sel, gain);                        // :85 (illegal: board unchanged, gain 0)
+    }
+    // :88 add_tile needs an empty cell; a board that changed always has one.  After an illegal move
+    // nothing is spawned (:91-95).
+    const uint32_t n_empty = add_tile(cells, w.w[0], lanemask(legal));
+    // :89 isend(): the board is full after the spawn exactly when it had one empty cell before it
+    bool end = false;
+    if (n_empty == 1u)                                             // :270-271
+        end = !has_equal_neighbours(cells);                        // :273-280
+    if (p.max_exp != 0 && highest(cells) == p.max_exp)             // :267-268
+        end = true;
+    const bool terminated = legal ? end : true;                    // :89, :94
+    // a spawned 4 raises the potential without scoring: deficit += 4 (bit 2 of d = bit 7 of byte 8)
+    const uint32_t inc = (legal && (w.w[0] & 0xffffu) > 58982u) ? 0x80u : 0u;
+    Board out = raw;
+    record_update(out, cells, inc);
+    const bool do_reset = terminated && p.auto_reset != 0;
 
     if (valid) {
-        store_board_nt(p.st.boards, i, bd);
-        __builtin_nontemporal_store(score, p.st.score + i);
-        if (p.reward)
-            __builtin_nontemporal_store(r.reward, p.reward + i);
+        if (!do_reset || (X & (X_OWNERSTORE | X_NOFIX)))
+            store_board_nt(p.st.boards, i, out);
+        if (p.reward)                                              // :90 / :95
+            __builtin_nontemporal_store(legal ? static_cast<float>(gain) : p.illegal_reward, p.reward + i);
         if (p.terminated)
-            __builtin_nontemporal_store(static_cast<uint8_t>(r.terminated ? 1 : 0), p.terminated + i);
+            __builtin_nontemporal_store(static_cast<uint8_t>(terminated ? 1 : 0), p.terminated + i);
         if (p.illegal)
-            __builtin_nontemporal_store(static_cast<uint8_t>(r.illegal ? 1 : 0), p.illegal + i);
+            __builtin_nontemporal_store(static_cast<uint8_t>(legal ? 0 : 1), p.illegal + i);
         if (p.highest)
-            __builtin_nontemporal_store(static_cast<uint8_t>(highest(r.terminal)), p.highest + i); // :97
+            __builtin_nontemporal_store(static_cast<uint8_t>(highest(cells)), p.highest + i); // :97
+        if (terminated && p.terminal_boards)
+            p.terminal_boards[i] = make_uint4(cells.r[0], cells.r[1], cells.r[2], cells.r[3]);
     }
-    r.terminated = r.terminated && valid;
-    WaveAcc acc;
-    record_episodes(p, i, r, acc, old_stats.max_score);
-    flush_wave_stats(p, i_raw, old_stats, acc);
+
+    if (X & X_NOFIX)
+        return;
+    // ---- finished episodes -> this wave's list in LDS
+    const bool fin = terminated && valid;
+    const unsigned long long fin_mask = __ballot(fin);
+    const uint32_t wave = tid >> 6;
+    if (fin_mask != 0ull) {
+        if (fin) {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fin_mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fin_mask), 0u));
+            const uint32_t e = wave * 64u + below;
+            const uint32_t lm = lanemask(legal);
+            // the reset uses words 1,2 after a legal move and 0,1 after an illegal one (:91-95)
+            sh.rec[e] = make_uint4(out.r[0], out.r[1], out.r[2], out.r[3]);
+            sh.aux[e] = make_uint4(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]),
+                                   tid | (do_reset ? 0x40000000u : 0u) | (legal ? 0u : 0x80000000u), 0u);
+        }
+        sh.count[wave] = static_cast<uint32_t>(__popcll(fin_mask)); // same value from every lane
+    }
+    // ---- arrival: the last wave of the block becomes the fixer (release/acquire at workgroup scope
+    //      orders the LDS lists against the counter)
+    uint32_t arrived = 0;
+    if ((tid & 63u) == 0u)
+        arrived = __hip_atomic_fetch_add(&sh.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != WAVES - 1)
+        return;
+    run_fixer<BLOCK>(p, sh);
 }
 
 // ------------------------------------------------------------------------- fused rollout
-// k steps of the synthetic random policy in ONE launch; the board never leaves registers.
+// k steps of the synthetic random policy in ONE launch; the board never leaves registers.  The record
+// is unpacked to (cells, score) once and packed once.
 __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p)
 {
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    const uint4 v = p.st.boards[i];
-    Board bd{{v.x, v.y, v.z, v.w}};
-    int32_t score = p.st.score[i];
+    const Board raw = load_board(p.st.boards, i);
+    Board bd = record_cells(raw);
+    int32_t score = static_cast<int32_t>(record_score(raw));
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
     WaveAcc acc;
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
@@ -191,26 +372,27 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
         r.terminated = r.terminated && valid;
         record_episodes(p, i, r, acc, 0);
     }
-    if (valid) {
-        p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-        p.st.score[i] = score;
-    }
-    flush_wave_stats(p, i_raw, p.st.wave_stats[i_raw >> 6], acc);
+    if (valid)
+        store_board(p.st.boards, i, make_record(bd, static_cast<uint32_t>(score)));
+    WaveStats *slot = p.st.wave_stats + (i_raw >> 6);
+    flush_wave_stats(slot, *slot, acc);
 }
 
 // ---------------------------------------------------------------- fused rollout with per-step I/O
 // The same k steps g2048_rollout performs with k launches, in ONE launch: boards and scores stay in
 // registers, each step reads action[j][i] and writes reward[j][i] / terminated[j][i] (stride = elements
-// between consecutive steps).  Bit-identical outputs; 6 B of traffic per env-step instead of 46.
+// between consecutive steps).  Bit-identical outputs; 6 B of traffic per env-step instead of 38.
 template <int ACT>
 __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p, uint64_t stride)
 {
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    Board bd = load_board_nt(p.st.boards, i);
-    int32_t score = p.st.score[i];
-    const WaveStats old_stats = p.st.wave_stats[i_raw >> 6];
+    const Board raw = load_board_nt(p.st.boards, i);
+    Board bd = record_cells(raw);
+    int32_t score = static_cast<int32_t>(record_score(raw));
+    WaveStats *slot = p.st.wave_stats + (i_raw >> 6);
+    const WaveStats old_stats = *slot;
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
     WaveAcc acc;
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
@@ -240,11 +422,9 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
         r.terminated = r.terminated && valid;
         record_episodes(p, i, r, acc, max(old_stats.max_score, acc.max_score));
     }
-    if (valid) {
-        store_board_nt(p.st.boards, i, bd);
-        p.st.score[i] = score;
-    }
-    flush_wave_stats(p, i_raw, old_stats, acc);
+    if (valid)
+        store_board_nt(p.st.boards, i, make_record(bd, static_cast<uint32_t>(score)));
+    flush_wave_stats(slot, old_stats, acc);
 }
 
 // ------------------------------------------------------------------------- numpy-RNG mode
@@ -268,11 +448,12 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    const uint4 v = p.st.boards[i];
-    Board bd{{v.x, v.y, v.z, v.w}};
-    int32_t score = p.st.score[i];
+    const Board raw = load_board(p.st.boards, i);
+    Board bd = record_cells(raw);
+    int32_t score = static_cast<int32_t>(record_score(raw));
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
-    const WaveStats old_stats = p.st.wave_stats[i_raw >> 6];
+    WaveStats *slot = p.st.wave_stats + (i_raw >> 6);
+    const WaveStats old_stats = *slot;
     uint32_t action;
     if constexpr (ACT == 0)
         action = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi).w[3] >> 30;
@@ -282,8 +463,7 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, p.auto_reset != 0);
 
     if (valid) {
-        p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-        p.st.score[i] = score;
+        store_board(p.st.boards, i, make_record(bd, static_cast<uint32_t>(score)));
         store_rng(p.st.rng, p.n, i, rng);
         if (p.reward)
             p.reward[i] = r.reward;
@@ -297,7 +477,7 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     r.terminated = r.terminated && valid;
     WaveAcc acc;
     record_episodes(p, i, r, acc, old_stats.max_score);
-    flush_wave_stats(p, i_raw, old_stats, acc);
+    flush_wave_stats(slot, old_stats, acc);
 }
 
 // numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.
@@ -324,8 +504,7 @@ __global__ void __launch_bounds__(kBlock) reset_numpy_kernel(const StepArgs p, c
     add_tile_numpy(bd, rng);      // :108
     add_tile_numpy(bd, rng);      // :109
     store_rng(p.st.rng, p.n, i, rng);
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-    p.st.score[i] = 0;            // :105
+    store_board(p.st.boards, i, make_record(bd, 0u)); // :105 score = 0
 }
 
 __global__ void __launch_bounds__(kBlock) add_tile_numpy_kernel(const StepArgs p)
@@ -333,14 +512,14 @@ __global__ void __launch_bounds__(kBlock) add_tile_numpy_kernel(const StepArgs p
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.n)
         return;
-    const uint4 v = p.st.boards[i];
-    Board bd{{v.x, v.y, v.z, v.w}};
+    const Board raw = load_board(p.st.boards, i);
+    Board bd = record_cells(raw);
     if (count_empty(bd) == 0)
         return;
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
     add_tile_numpy(bd, rng);
     store_rng(p.st.rng, p.n, i, rng);
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    store_board(p.st.boards, i, make_record(bd, record_score(raw)));
 }
 
 // ---------------------------------------------------------------------------------- reset
@@ -361,9 +540,7 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const StepArgs p, uint32_
         w2 = philox4x32_10(p.t_lo, p.t_hi, b, (first_slot >> 2) + 1u, p.seed_lo, p.seed_hi).w[0];
     else
         w2 = select_word(w, s + 1u);
-    const Board bd = fresh_board(w1, w2);
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
-    p.st.score[i] = 0; // :105
+    store_board(p.st.boards, i, fresh_record(w1, w2)); // score 0 (:105) is part of the record
 }
 
 // ------------------------------------------------------------------------- game primitives
@@ -375,8 +552,8 @@ __global__ void __launch_bounds__(kBlock) move_kernel(uint4 *boards, uint32_t n,
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n)
         return;
-    const uint4 v = boards[i];
-    Board bd{{v.x, v.y, v.z, v.w}};
+    const Board raw = load_board(boards, i);
+    Board bd = record_cells(raw);
     uint32_t gain;
     const bool legal = move(bd, load_action<ACT>(actions, i, 0u), gain);
     if (score_out)
@@ -384,7 +561,7 @@ __global__ void __launch_bounds__(kBlock) move_kernel(uint4 *boards, uint32_t n,
     if (legal_out)
         legal_out[i] = legal ? 1 : 0;
     if (!trial && legal)
-        boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+        store_board(boards, i, make_record(bd, record_score(raw))); // self.score is not touched by move()
 }
 
 // Game2048Env.isend (game2048_env.py:262-280) and highest (:190-192).
@@ -394,8 +571,7 @@ __global__ void __launch_bounds__(kBlock) query_kernel(const uint4 *boards, uint
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n)
         return;
-    const uint4 v = boards[i];
-    const Board bd{{v.x, v.y, v.z, v.w}};
+    const Board bd = record_cells(load_board(boards, i));
     if (isend_out)
         isend_out[i] = is_end(bd, max_exp) ? 1 : 0;
     if (highest_out)
@@ -408,13 +584,57 @@ __global__ void __launch_bounds__(kBlock) add_tile_kernel(const StepArgs p, uint
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.n)
         return;
-    const uint4 v = p.st.boards[i];
-    Board bd{{v.x, v.y, v.z, v.w}};
+    const Board raw = load_board(p.st.boards, i);
+    Board bd = record_cells(raw);
     if (count_empty(bd) == 0) // the reference asserts here (:176)
         return;
     const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, slot >> 2, p.seed_lo, p.seed_hi);
     add_tile(bd, select_word(w, slot & 3u));
-    p.st.boards[i] = make_uint4(bd.r[0], bd.r[1], bd.r[2], bd.r[3]);
+    store_board(p.st.boards, i, make_record(bd, record_score(raw)));
+}
+
+// ------------------------------------------------------------- records <-> plain boards / scores
+// get_board / set_board (game2048_env.py:282-288) and self.score for the whole batch.
+__global__ void __launch_bounds__(kBlock) export_boards_kernel(const uint4 *records, uint32_t n, uint4 *cells_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n)
+        store_board(cells_out, i, record_cells(load_board(records, i)));
+}
+
+__global__ void __launch_bounds__(kBlock) import_boards_kernel(uint4 *records, uint32_t n, const uint4 *cells_in)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const Board in = load_board(cells_in, i);
+    const Board cells{{in.r[0] & kCellBits, in.r[1] & kCellBits, in.r[2] & kCellBits, in.r[3] & kCellBits}};
+    store_board(records, i, make_record(cells, record_score(load_board(records, i)))); // score untouched (:286-288)
+}
+
+__global__ void __launch_bounds__(kBlock) export_scores_kernel(const uint4 *records, uint32_t n, int32_t *scores_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n)
+        scores_out[i] = static_cast<int32_t>(record_score(load_board(records, i)));
+}
+
+__global__ void __launch_bounds__(kBlock) import_scores_kernel(uint4 *records, uint32_t n, const int32_t *scores_in)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const Board cells = record_cells(load_board(records, i));
+    store_board(records, i, make_record(cells, static_cast<uint32_t>(scores_in[i]) & kScoreMask));
+}
+
+__global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState st, uint32_t n, uint32_t n_slots)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n)
+        st.last_score[i] = 0;
+    if (i < n_slots)
+        st.wave_stats[i] = WaveStats{0u, 0u, 0ull, 0, 0};
 }
 
 // ------------------------------------------------------------------------ synthetic policy
@@ -433,7 +653,7 @@ __global__ void __launch_bounds__(kBlock) fill_actions_kernel(uint8_t *out, uint
 }
 
 // ---------------------------------------------------------------------------------- onehot
-// stack() (game2048_env.py:17-32): board -> (16,4,4), channel c = (exponent == c).  One lane writes
+// stack() (game2048_env.py:17-32): board record -> (16,4,4), channel c = (exponent == c).  One lane writes
 // one 16-byte chunk of the output, so every store is a coalesced dwordx4:
 //   u8 : chunk = one channel (16 cells)            16 chunks / board
 //   f16: chunk = half a channel (8 cells)          32 chunks / board
@@ -450,12 +670,12 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
         const uint64_t board = g >> 4;
         const uint32_t splat = static_cast<uint32_t>(g & 15u) * 0x01010101u;
         const uint4 v = boards[board];
-        out[g] = make_uint4(z80(v.x ^ splat) >> 7, z80(v.y ^ splat) >> 7, z80(v.z ^ splat) >> 7,
-                            z80(v.w ^ splat) >> 7);
+        out[g] = make_uint4(z80(v.x ^ splat) >> 7, z80(v.y ^ splat) >> 7, z80((v.z & kCellBits) ^ splat) >> 7,
+                            z80((v.w & kCellBits) ^ splat) >> 7);
     } else if constexpr (OBS == 1) {
         const uint64_t board = g >> 5;
         const uint32_t c = static_cast<uint32_t>(g >> 1) & 15u, half = static_cast<uint32_t>(g) & 1u;
-        const uint32_t r0 = cells[board * 4 + half * 2], r1 = cells[board * 4 + half * 2 + 1];
+        const uint32_t r0 = cells[board * 4 + half * 2] & kCellBits, r1 = cells[board * 4 + half * 2 + 1] & kCellBits;
         uint32_t h[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -466,7 +686,7 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
     } else {
         const uint64_t board = g >> 6;
         const uint32_t c = static_cast<uint32_t>(g >> 2) & 15u, row = static_cast<uint32_t>(g) & 3u;
-        const uint32_t r = cells[board * 4 + row];
+        const uint32_t r = cells[board * 4 + row] & kCellBits;
         uint32_t f[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -529,30 +749,88 @@ __global__ void __launch_bounds__(kBlock) augment_kernel(const uint4 *__restrict
     }
 }
 
+// ------------------------------------------------------------------------- canonicalisation
+// Symmetric-board canonicalisation: of the eight symmetries training_data.augment()
+// generates (training_data.py:257-299, same order: variant = 2 * quarter_turns + hflip), keep the one
+// whose 16 cells, read row-major as bytes, are lexicographically smallest (ties: the lowest variant
+// index); the action is remapped and the next board transformed by the same symmetry.  In place.
+// Row-major byte order = compare r[0] first, byte 0 most significant: bswap makes that an integer compare.
+__device__ __forceinline__ bool board_less(const Board &a, const Board &b)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = __builtin_bswap32(a.r[k]), y = __builtin_bswap32(b.r[k]);
+        if (x != y)
+            return x < y;
+    }
+    return false;
+}
+
+__device__ __forceinline__ Board symmetry(const Board &b, uint32_t variant)
+{
+    return rotate_board((variant & 1u) ? hflip_board(b) : b, variant >> 1);
+}
+
+__global__ void __launch_bounds__(kBlock) canonicalize_kernel(uint4 *boards, uint4 *next_boards, uint8_t *actions,
+                                                              uint32_t n, uint8_t *sym_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const Board b = load_board(boards, i);
+    Board best = b;
+    uint32_t best_v = 0;
+#pragma unroll
+    for (uint32_t v = 1; v < 8; ++v) {
+        const Board c = symmetry(b, v);
+        if (board_less(c, best)) {
+            best = c;
+            best_v = v;
+        }
+    }
+    store_board(boards, i, best);
+    if (next_boards)
+        store_board(next_boards, i, symmetry(load_board(next_boards, i), best_v));
+    if (actions) {
+        uint32_t a = actions[i] & 3u;
+        if (best_v & 1u)
+            a = (a == 1u) ? 3u : (a == 3u ? 1u : a); // hflip swaps right <-> left (:262-267)
+        actions[i] = static_cast<uint8_t>((a + (best_v >> 1)) & 3u); // a clockwise quarter turn adds 1 (:276)
+    }
+    if (sym_out)
+        sym_out[i] = static_cast<uint8_t>(best_v);
+}
+
 // ----------------------------------------------------------------------------------- stats
-// Reduce the per-wave accumulators (and the highest tile on any board) to one StatsOut.
-// Block-level tree in LDS first, then ONE set of atomics per block (a single hot word serialises at
-// ~88 atomics/us on this chip, so per-wave atomics to one address would take hundreds of us).
+// Reduce the episode accumulators, the highest tile on any board and the histogram of the boards'
+// highest tiles (what ppo_train.py:77-81 logs per finished episode, here for the live boards) to one
+// StatsOut.  Block-level tree in LDS first, then ONE set of atomics per block (a single hot word
+// serialises at ~88 atomics/us on this chip, so per-wave atomics to one address would take hundreds of us).
 __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
                                                        StatsOut *out)
 {
     __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock];
     __shared__ int s_max[kBlock], s_exp[kBlock];
+    __shared__ unsigned int s_hist[32];
     unsigned long long episodes = 0, illegal = 0, score_sum = 0;
     int max_score = 0, max_exp = 0;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 32u)
+        s_hist[tid] = 0u;
+    __syncthreads();
     const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t wv = blockIdx.x * kBlock + threadIdx.x; wv < n_waves; wv += stride) {
+    for (uint32_t wv = blockIdx.x * kBlock + tid; wv < n_waves; wv += stride) {
         const WaveStats ws = st.wave_stats[wv];
         episodes += ws.episodes;
         illegal += ws.illegal_ends;
         score_sum += ws.score_sum;
         max_score = max(max_score, ws.max_score);
     }
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint4 v = st.boards[i];
-        max_exp = max(max_exp, static_cast<int>(highest(Board{{v.x, v.y, v.z, v.w}})));
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += stride) {
+        const int h = static_cast<int>(highest(record_cells(load_board(st.boards, i))));
+        max_exp = max(max_exp, h);
+        atomicAdd(&s_hist[h & 31], 1u);
     }
-    const uint32_t tid = threadIdx.x;
     s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_max[tid] = max_score; s_exp[tid] = max_exp;
     __syncthreads();
     for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
@@ -572,6 +850,8 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
         atomicMax(&out->max_score, s_max[0]);
         atomicMax(&out->max_exp, static_cast<unsigned int>(s_exp[0]));
     }
+    if (tid < 32u && s_hist[tid] != 0u)
+        atomicAdd(&out->highest_hist[tid], s_hist[tid]);
 }
 
 // -------------------------------------------------------------------------------- launchers
@@ -589,12 +869,12 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
 {
     if (a.n == 0)
         return hipSuccess;
-    const dim3 g = grid_for(a.n), b(kBlock);
+    const dim3 g((a.n + kStepBlock - 1) / kStepBlock), b(kStepBlock);
     switch (action_dtype) {
-    case 0: hipLaunchKernelGGL(step_kernel<0>, g, b, 0, s, a); break;
-    case 1: hipLaunchKernelGGL(step_kernel<1>, g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(step_kernel<2>, g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(step_kernel<3>, g, b, 0, s, a); break;
+    case 0: hipLaunchKernelGGL((step_kernel<0, kStepBlock>), g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((step_kernel<1, kStepBlock>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((step_kernel<2, kStepBlock>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((step_kernel<3, kStepBlock>), g, b, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -755,6 +1035,55 @@ hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hi
     if (blocks > 512u)
         blocks = 512u;
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, dev_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(export_boards_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, cells_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(import_boards_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, cells_in);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *scores_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(export_scores_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, scores_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(import_scores_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, scores_in);
+    return hipGetLastError();
+}
+
+hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(clear_stats_kernel, grid_for(n), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u);
+    return hipGetLastError();
+}
+
+hipError_t launch_canonicalize(uint4 *boards, uint4 *next_boards, uint8_t *actions, uint32_t n, uint8_t *sym_out,
+                               hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(canonicalize_kernel, grid_for(n), dim3(kBlock), 0, s, boards, next_boards, actions, n, sym_out);
     return hipGetLastError();
 }
 

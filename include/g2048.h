@@ -18,6 +18,14 @@
  *  - A board is 16 x uint8 exponents, row-major: 0 = empty, k = tile 2^k (reference: int64 tile
  *    values in a 4x4 ndarray, game2048_env.py:104).  Actions: 0 up, 1 right, 2 down, 3 left
  *    (game2048_env.py:196); only the low two bits of an action are used.
+ *  - What the engine keeps per board in HBM is one 16-byte RECORD: bits [4:0] of byte j are the exponent
+ *    of cell j, and the three spare bits [7:5] of bytes 8..15 hold the 24-bit "score deficit"
+ *    d = (potential - score) mod 2^24, potential = sum over tiles of (e - 1) * 2^e, so that
+ *    self.score (game2048_env.py:46,86,105) = potential - d.  A merge raises the potential by exactly
+ *    what it scores, so a step only touches d when it spawns a 4 (d += 4), and a step reads and writes
+ *    exactly 16 bytes per board -- there is no separate score array.  g2048_get/set_boards and
+ *    g2048_get/set_scores convert to and from plain arrays; g2048_records_ptr exposes the records
+ *    (cells = byte & 0x1f).  Scores are exact in 0 .. 2^24 - 1.
  *  - An engine is not thread-safe; use one engine per device per process.
  *
  * Randomness: the "spawn stream" (oracle/g2048_oracle.h has the same text and is the checker)
@@ -76,7 +84,12 @@ typedef struct {
     int64_t score_sum;       /* sum of their final merge scores (game2048_env.py:86) */
     int32_t max_score;       /* best final score */
     uint32_t max_exp;        /* highest exponent currently on any board */
+    uint32_t highest_hist[32]; /* highest_hist[k] = boards whose highest tile (game2048_env.py:190-192) is 2^k
+                                * right now (k = 0: empty board) -- what ppo_train.py:77-81 tallies */
 } g2048_stats;
+
+typedef struct g2048_comm g2048_comm;
+#define G2048_COMM_ID_BYTES 128
 
 const char *g2048_last_error(void);
 /* Library / ABI version, bumped on any signature change. */
@@ -89,8 +102,9 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
 int g2048_destroy(g2048_engine *e);
 
 /* gym.Env.reset(seed=...) seeding half (game2048_env.py:103): restart the spawn stream (t = 0) and
- * clear the episode statistics (last_score, per-wave accumulators).  Synchronous (hipMemset). */
-int g2048_seed(g2048_engine *e, uint64_t seed);
+ * clear the episode statistics (last_score, episode accumulators) with a kernel enqueued on `stream`
+ * (ordered against steps already enqueued there; no host synchronisation). */
+int g2048_seed(g2048_engine *e, uint64_t seed, void *stream);
 int g2048_get_clock(const g2048_engine *e, uint64_t *t);
 int g2048_set_clock(g2048_engine *e, uint64_t t);
 uint64_t g2048_num_boards(const g2048_engine *e);
@@ -152,11 +166,16 @@ int g2048_fill_random_actions(const g2048_engine *e, uint64_t t_first, uint32_t 
 int g2048_onehot(const g2048_engine *e, void *out, int32_t obs_dtype, void *stream);
 
 /* get_board / set_board (game2048_env.py:282-288) for the whole batch; `buf` is [n][16] uint8
- * exponents in host or device memory (hipMemcpyDefault). set_boards does not touch the scores. */
+ * exponents in host or device memory (device buffers 16-byte aligned).  A conversion kernel runs
+ * between the records and `buf` (through an engine-owned staging buffer when `buf` is host memory).
+ * Host buffers: the copy is synchronous.  Device buffers: everything is enqueued on `stream`, no host
+ * synchronisation.  set_boards does not touch the scores; exponents are taken mod 32. */
 int g2048_get_boards(const g2048_engine *e, uint8_t *buf, void *stream);
 int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream);
 
-/* Episodic merge score self.score (game2048_env.py:46,86,105): int32[n], host or device. */
+/* Episodic merge score self.score (game2048_env.py:46,86,105): int32[n], host or device; computed
+ * from / folded into the records by a kernel.  Scores must lie in 0 .. 2^24 - 1 (host buffers are
+ * checked, device buffers are taken mod 2^24). */
 int g2048_get_scores(const g2048_engine *e, int32_t *buf, void *stream);
 int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream);
 
@@ -164,10 +183,10 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream);
  * terminates; 0 before the first one): int32[n], host or device. */
 int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream);
 
-/* Raw device pointers of the engine-owned state for zero-copy views (boards: uint8[n][16],
- * scores: int32[n], last_score: int32[n]).  Valid until g2048_destroy. */
-void *g2048_boards_ptr(const g2048_engine *e);
-void *g2048_scores_ptr(const g2048_engine *e);
+/* Raw device pointers of the engine-owned state for zero-copy views: the board RECORDS
+ * (uint8[n][16]; cell = byte & 0x1f, see "RECORD" above) and last_score (int32[n]).  Valid until
+ * g2048_destroy. */
+void *g2048_records_ptr(const g2048_engine *e);
 void *g2048_last_score_ptr(const g2048_engine *e);
 
 /* Reduce the episode bookkeeping on the device and copy the result to *out (synchronises `stream`). */
@@ -201,7 +220,35 @@ int g2048_augment(const uint8_t *boards, const uint8_t *next_boards, const uint8
  * only models; its env state hooks are get_board/set_board (game2048_env.py:282-288). */
 uint64_t g2048_state_bytes(const g2048_engine *e);
 int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream);
-int g2048_set_state(g2048_engine *e, const void *host_buf, void *stream);
+/* blob_bytes = size of host_buf; magic, board count, size and header fields are validated. */
+int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, void *stream);
+
+/* Symmetric-board canonicalisation (the counterpart of g2048_augment): every board (plain uint8[n][16]
+ * exponents, device pointer, 16-byte aligned) is replaced IN PLACE by the lexicographically smallest
+ * (row-major bytes) of its eight symmetries -- the ones training_data.py:257-299 generates, same index
+ * order: variant = 2 * clockwise_quarter_turns + hflip; ties keep the lowest variant.  When non-NULL,
+ * next_boards[n][16] gets the same symmetry, actions[n] (uint8) are remapped (hflip swaps 1<->3, a
+ * clockwise quarter turn adds 1 mod 4) and symmetry_out[n] receives the variant applied.  Needs no engine. */
+int g2048_canonicalize(uint8_t *boards, uint8_t *next_boards, uint8_t *actions, uint64_t n, uint8_t *symmetry_out,
+                       void *stream);
+
+/* ---- the collective: all-gather of episodic returns, RCCL over xGMI (no counterpart in the reference,
+ * which has no multi-device code).  RCCL is loaded on the first g2048_comm_* call.
+ *
+ * One process per GPU: rank 0 calls g2048_comm_unique_id and hands the 128 bytes to the other ranks by
+ * any means (torch.distributed.broadcast, MPI, a file); every rank then calls g2048_comm_create
+ * (ncclCommInitRank).  g2048_allgather_returns enqueues ONE ncclAllGather of the engine's last_score
+ * (int32[n], n equal on all ranks) into out[world * n] (device memory) on `stream`. */
+int g2048_comm_unique_id(uint8_t id[G2048_COMM_ID_BYTES]);
+int g2048_comm_create(int world, int rank, const uint8_t id[G2048_COMM_ID_BYTES], int device, g2048_comm **out);
+int g2048_comm_destroy(g2048_comm *c);
+int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, void *stream);
+/* One process driving several GPUs: engines[r] on distinct devices with equal board counts; a
+ * communicator set is built with ncclCommInitAll, every engine's last_score is all-gathered into
+ * outs[r][n_engines * n] (device memory on engine r's device) on streams[r] (NULL = null streams), the
+ * streams are synchronised and the communicators destroyed. */
+int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, int32_t *const *outs,
+                                  void *const *streams);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,149 @@ void hostcheck_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t
     }
 }
 
+// ---- the RECORD layout and the per-step kernel's flow (step_kernel + its block fixer in
+// g2048_kernels.hip), one board at a time: state lives in `records` (16 B per board: cells + packed
+// score deficit); the plain boards / scores of the batch struct are exported after every call so
+// the test can compare them with the oracle's.
+static const uint32_t kLutHost[32] = {G2048_MOVE_LUT_WORDS};
+
+static MoveSel host_move_sel(uint32_t action)
+{
+    const uint32_t *r = kLutHost + 8 * (action & 3u);
+    return MoveSel{r[0], r[1], r[2], r[3], r[4], r[5]};
+}
+
+static void export_record(g2048o_batch *s, uint64_t i, const Board &rec)
+{
+    store_board(s->boards + 16 * i, record_cells(rec));
+    s->score[i] = (int32_t)record_score(rec);
+}
+
+int hostcheck_move_sel(const uint8_t in[16], uint32_t action, uint8_t out[16], uint32_t *score)
+{
+    Board bd = load_board(in);
+    const bool legal = move_sel(bd, host_move_sel(action), *score);
+    store_board(out, bd);
+    return legal;
+}
+
+uint32_t hostcheck_potential(const uint8_t in[16]) { return potential(load_board(in)); }
+
+void hostcheck_make_record(const uint8_t cells[16], uint32_t score, uint8_t rec[16])
+{
+    store_board(rec, make_record(load_board(cells), score));
+}
+
+uint32_t hostcheck_record_score(const uint8_t rec[16]) { return record_score(load_board(rec)); }
+uint32_t hostcheck_record_deficit(const uint8_t rec[16]) { return record_deficit(load_board(rec)); }
+
+// record_update with an arbitrary number of "+4" carries (exercises the ripple through the cell bits)
+void hostcheck_record_bump(uint8_t rec[16], uint32_t times)
+{
+    Board raw = load_board(rec);
+    for (uint32_t k = 0; k < times; ++k)
+        record_update(raw, record_cells(raw), 0x80u);
+    store_board(rec, raw);
+}
+
+void hostcheck_reset_records(g2048o_batch *s, uint8_t *records, uint64_t n, uint64_t seed, uint64_t t,
+                             uint64_t board_offset, uint32_t first_slot)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t b = (uint32_t)(board_offset + i);
+        const Words w = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), b, first_slot >> 2, (uint32_t)seed,
+                                      (uint32_t)(seed >> 32));
+        const uint32_t sl = first_slot & 3u;
+        const uint32_t w1 = select_word(w, sl);
+        uint32_t w2;
+        if (sl == 3u)
+            w2 = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), b, (first_slot >> 2) + 1u, (uint32_t)seed,
+                               (uint32_t)(seed >> 32)).w[0];
+        else
+            w2 = select_word(w, sl + 1u);
+        const Board rec = fresh_record(w1, w2);
+        store_board(records + 16 * i, rec);
+        export_record(s, i, rec);
+        s->ep_start[i] = (uint32_t)t;
+    }
+}
+
+void hostcheck_step_records(g2048o_batch *s, uint8_t *records, uint64_t n, uint64_t seed, uint64_t t,
+                            uint64_t board_offset, float illegal_move_reward, int max_exp_i, int auto_reset)
+{
+    const uint32_t max_exp = (uint32_t)max_exp_i;
+    for (uint64_t i = 0; i < n; ++i) {
+        // ---- owner lane (step_kernel)
+        const Board raw = load_board(records + 16 * i);
+        const Words w = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(board_offset + i), 0u,
+                                      (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t action = s->actions ? (s->actions[i] & 3u) : (w.w[3] >> 30);
+        Board cells = record_cells(raw);
+        uint32_t gain;
+        const bool legal = move_sel(cells, host_move_sel(action), gain);
+        const uint32_t n_empty = add_tile(cells, w.w[0], lanemask(legal));
+        bool end = false;
+        if (n_empty == 1u)
+            end = !has_equal_neighbours(cells);
+        if (max_exp != 0 && highest(cells) == max_exp)
+            end = true;
+        const bool terminated = legal ? end : true;
+        const uint32_t inc = (legal && (w.w[0] & 0xffffu) > 58982u) ? 0x80u : 0u;
+        Board out = raw;
+        record_update(out, cells, inc);
+        const bool do_reset = terminated && auto_reset != 0;
+        if (!do_reset)
+            store_board(records + 16 * i, out);
+        if (s->reward) s->reward[i] = legal ? (float)gain : illegal_move_reward;
+        if (s->terminated) s->terminated[i] = terminated;
+        if (s->illegal) s->illegal[i] = !legal;
+        if (s->highest) s->highest[i] = (uint8_t)highest(cells);
+        if (terminated) {
+            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, cells);
+            // ---- fixer lane (run_fixer): entry = {out, w1, w2, flags}
+            const uint32_t lm = lanemask(legal);
+            const uint32_t w1 = bfi(lm, w.w[1], w.w[0]), w2 = bfi(lm, w.w[2], w.w[1]);
+            s->last_score[i] = (int32_t)record_score(out);
+            s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
+            s->ep_count[i] += 1;
+            if (do_reset) {
+                store_board(records + 16 * i, fresh_record(w1, w2));
+                s->ep_start[i] = (uint32_t)t;
+            }
+        }
+        export_record(s, i, load_board(records + 16 * i));
+    }
+}
+
+// the fused kernels' way through the record: unpack once, step_env, pack
+void hostcheck_step_records_unpacked(g2048o_batch *s, uint8_t *records, uint64_t n, uint64_t seed, uint64_t t,
+                                     uint64_t board_offset, float illegal_move_reward, int max_exp, int auto_reset)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const Board raw = load_board(records + 16 * i);
+        Board bd = record_cells(raw);
+        int32_t score = (int32_t)record_score(raw);
+        const Words w = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(board_offset + i), 0u,
+                                      (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t action = s->actions ? (s->actions[i] & 3u) : (w.w[3] >> 30);
+        const StepResult r = step_env(bd, score, action, w, illegal_move_reward, (uint32_t)max_exp, auto_reset != 0);
+        if (s->reward) s->reward[i] = r.reward;
+        if (s->terminated) s->terminated[i] = r.terminated;
+        if (s->illegal) s->illegal[i] = r.illegal;
+        if (s->highest) s->highest[i] = (uint8_t)highest(r.terminal);
+        if (r.terminated) {
+            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, r.terminal);
+            s->last_score[i] = r.terminal_score;
+            s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
+            s->ep_count[i] += 1;
+            if (auto_reset) s->ep_start[i] = (uint32_t)t;
+        }
+        const Board rec = make_record(bd, (uint32_t)score);
+        store_board(records + 16 * i, rec);
+        export_record(s, i, rec);
+    }
+}
+
 // ---- numpy-compatible RNG mode (g2048_pcg64.h); rng = [n][5] uint64 as in the oracle
 static Pcg64 load_rng(const g2048o_pcg64 *r) { return Pcg64{r->state_lo, r->state_hi, r->inc_lo, r->inc_hi, r->buf}; }
 static void store_rng(g2048o_pcg64 *r, const Pcg64 &p)

@@ -128,3 +128,114 @@ def test_reset_slots(host_check):
         a.reset(first_slot=first_slot, new_transaction=False)
         b.reset(first_slot=first_slot, new_transaction=False)
         assert np.array_equal(a.boards, b.boards), first_slot
+
+
+# ------------------------------------------------------------------ board RECORD (cells + score deficit)
+
+class HostRecordBatch(OracleBatch):
+    """Mirror of step_kernel + its block fixer (g2048_kernels.hip) on the host: the state is the array
+    of 16-byte records; plain boards and scores are exported after every call."""
+
+    def __init__(self, hc, n, seed=0, board_offset=0, unpacked=False):
+        super().__init__(n, seed, board_offset)
+        self.hc = hc
+        self.records = np.zeros((n, 16), np.uint8)
+        self.step_fn = hc.hostcheck_step_records_unpacked if unpacked else hc.hostcheck_step_records
+        u64, vp = C.c_uint64, C.c_void_p
+        hc.hostcheck_reset_records.restype = None
+        hc.hostcheck_reset_records.argtypes = [C.POINTER(_Batch), vp, u64, u64, u64, u64, C.c_uint32]
+        for f in (hc.hostcheck_step_records, hc.hostcheck_step_records_unpacked):
+            f.restype = None
+            f.argtypes = [C.POINTER(_Batch), vp, u64, u64, u64, u64, C.c_float, C.c_int, C.c_int]
+
+    def reset(self, first_slot=0, new_transaction=None):
+        if new_transaction is None:
+            new_transaction = not self.fresh
+        if new_transaction:
+            self.t += 1
+        self.fresh = False
+        b = self._batch()
+        self.hc.hostcheck_reset_records(C.byref(b), self.records.ctypes.data, self.n, self.seed, self.t,
+                                        self.board_offset, first_slot)
+
+    def step(self, actions=None, auto_reset=True):
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        self.t += 1
+        self.fresh = False
+        b = self._batch(actions)
+        self.step_fn(C.byref(b), self.records.ctypes.data, self.n, self.seed, self.t, self.board_offset,
+                     self.illegal_move_reward, self.max_exp, int(auto_reset))
+
+
+def test_move_lut(host_check):
+    """move_sel (per-lane perm selectors) == move (transpose + selects) == the reference's move table."""
+    m = load_golden("move_table")
+    for i in range(len(m["boards"])):
+        p = np.ascontiguousarray(m["boards"][i]).ctypes.data_as(U8P)
+        for d in range(4):
+            out = np.zeros(16, np.uint8)
+            sc = C.c_uint32()
+            legal = host_check.hostcheck_move_sel(p, d, out.ctypes.data_as(U8P), C.byref(sc))
+            assert legal == m["legal"][i, d]
+            assert np.array_equal(out, m["new"][i, d]) and sc.value == m["score"][i, d]
+
+
+def test_potential_and_record_packing(host_check):
+    rng = np.random.default_rng(8)
+    host_check.hostcheck_potential.restype = C.c_uint32
+    host_check.hostcheck_record_score.restype = C.c_uint32
+    host_check.hostcheck_record_deficit.restype = C.c_uint32
+    for trial in range(3000):
+        cells = rng.integers(0, 18 if trial % 3 else 32, 16).astype(np.uint8)
+        cells[rng.random(16) < 0.3] = 0
+        e = cells.astype(np.int64)
+        pot = int(np.where(e > 0, (e - 1) << e, 0).sum()) & 0xFFFFFFFF
+        assert host_check.hostcheck_potential(cells.ctypes.data_as(U8P)) == pot
+        score = int(rng.integers(0, 1 << 24))
+        rec = np.zeros(16, np.uint8)
+        host_check.hostcheck_make_record(cells.ctypes.data_as(U8P), score, rec.ctypes.data_as(U8P))
+        assert np.array_equal(rec & 0x1F, cells) and not (rec[:8] & 0xE0).any()
+        assert host_check.hostcheck_record_score(rec.ctypes.data_as(U8P)) == score
+        d = host_check.hostcheck_record_deficit(rec.ctypes.data_as(U8P))
+        assert d == (pot - score) & 0xFFFFFF
+        # bit k of d sits in bit 5 + k % 3 of byte 8 + k // 3 (include/g2048.h)
+        spread = sum(((int(rec[8 + k // 3]) >> (5 + k % 3)) & 1) << k for k in range(24))
+        assert spread == d
+        # "+4" carries ripple through the cell bits and wrap mod 2^24
+        times = int(rng.integers(1, 40))
+        host_check.hostcheck_record_bump(rec.ctypes.data_as(U8P), times)
+        assert np.array_equal(rec & 0x1F, cells)
+        assert host_check.hostcheck_record_score(rec.ctypes.data_as(U8P)) == (score - 4 * times) & 0xFFFFFF
+    # carry chain across the whole field: d = 2^24 - 4, +4 -> 0
+    cells = np.full(16, 31, np.uint8)
+    rec = np.zeros(16, np.uint8)
+    pot = (16 * (30 << 31)) & 0xFFFFFFFF
+    host_check.hostcheck_make_record(cells.ctypes.data_as(U8P), (pot - (1 << 24) + 4) & 0xFFFFFF, rec.ctypes.data_as(U8P))
+    assert host_check.hostcheck_record_deficit(rec.ctypes.data_as(U8P)) == (1 << 24) - 4
+    host_check.hostcheck_record_bump(rec.ctypes.data_as(U8P), 1)
+    assert host_check.hostcheck_record_deficit(rec.ctypes.data_as(U8P)) == 0 and np.array_equal(rec & 0x1F, cells)
+
+
+@pytest.mark.parametrize("unpacked", [False, True])
+@pytest.mark.parametrize("name", TRAJECTORIES)
+def test_golden_trajectories_records(host_check, name, unpacked):
+    replay_trajectory(lambda n, seed, off: HostRecordBatch(host_check, n, seed, off, unpacked), load_golden(name))
+
+
+@pytest.mark.parametrize("seed,offset,irw,max_exp,auto_reset", [
+    (11, 0, 0.0, 0, True), (12, (1 << 32) - 4096, -1.0, 0, True), (13, 77, -2.5, 5, True), (14, 0, 0.0, 0, False)])
+def test_random_rollouts_records_vs_oracle(host_check, seed, offset, irw, max_exp, auto_reset):
+    n, steps = 4096, 96
+    a, b = OracleBatch(n, seed, offset), HostRecordBatch(host_check, n, seed, offset)
+    for o in (a, b):
+        o.illegal_move_reward, o.max_exp = irw, max_exp
+        o.reset()
+    assert np.array_equal(a.boards, b.boards) and np.array_equal(a.score, b.score)
+    for s in range(steps):
+        for o in (a, b):
+            o.step(None, auto_reset=auto_reset)
+        for f in ("boards", "score", "reward", "terminated", "illegal", "highest", "last_score", "last_len",
+                  "ep_count", "ep_start", "terminal_boards"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (f, s)
+    assert a.ep_count.sum() > 100

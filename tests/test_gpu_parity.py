@@ -282,9 +282,13 @@ def test_masked_reset_set_state_and_views(torch_cuda):
     keep = mask.numpy() == 0
     assert np.array_equal(after[keep], before[keep]) and np.array_equal(e.get_scores()[keep], scores_before[keep])
     assert ((after[~keep] != 0).sum(axis=(1, 2)) == 2).all() and (e.get_scores()[~keep] == 0).all()
-    # zero-copy views alias engine memory
-    v = e.boards()
-    assert v.data_ptr() == e._lib.g2048_boards_ptr(e._h) and np.array_equal(v.cpu().numpy(), after)
+    # the zero-copy view aliases the engine's records: cells in the low five bits, the packed score
+    # deficit only in the spare bits of bytes 8..15 (include/g2048.h)
+    v = e.records()
+    raw = v.cpu().numpy()
+    assert v.data_ptr() == e._lib.g2048_records_ptr(e._h) and np.array_equal(raw & 0x1F, after.reshape(n, 16))
+    assert not (raw[:, :8] & 0xE0).any()
+    assert np.array_equal(e.boards().cpu().numpy(), after) and np.array_equal(e.scores().cpu().numpy(), e.get_scores())
     # checkpoint / resume reproduces the continuation exactly
     state = e.state_dict()
     for _ in range(5):
