@@ -161,10 +161,10 @@ def main():
         torch.cuda.synchronize()
 
     def gather_returns():
-        local = eng.last_scores()
+        local = eng.last_scores()                  # int32[B] returns, from the terminal records (one kernel)
         if backend != "nccl" and world > 1:        # gloo smoke test: collectives on host copies
             return allgather_returns(local.cpu(), shard)
-        return allgather_returns(local.clone(), shard)   # a torch-owned send buffer for RCCL
+        return allgather_returns(local, shard)
 
     # ---- warm-up: W untimed steps (own small buffers), then inputs for the timed K steps
     if W > 0:
@@ -220,7 +220,7 @@ def main():
                      "traffic": traffic.get("bytes_per_launch") if (traffic and B == (1 << 20)) else None,
                      "kernel": "g2048::step_kernel<1>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us},
-        "episodes_finished": int(stats["episodes"]), "mean_episode_score": stats["mean_score"],
+        "episodes_finished": int(stats["episodes"]), "mean_last_episode_score": stats["mean_last_score"],
     }
 
     if rank == 0 and world == 1 and not args.no_extras:

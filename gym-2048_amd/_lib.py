@@ -38,8 +38,9 @@ class Stats(C.Structure):
     _fields_ = [
         ("episodes", C.c_uint64),
         ("illegal_ends", C.c_uint64),
-        ("score_sum", C.c_int64),
-        ("max_score", C.c_int32),
+        ("last_count", C.c_uint64),
+        ("last_score_sum", C.c_int64),
+        ("last_score_max", C.c_int32),
         ("max_exp", C.c_uint32),
         ("highest_hist", C.c_uint32 * 32),
     ]
@@ -77,7 +78,7 @@ SIGNATURES = {
     "g2048_set_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_last_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_records_ptr": (C.c_void_p, [_E]),
-    "g2048_last_score_ptr": (C.c_void_p, [_E]),
+    "g2048_last_records_ptr": (C.c_void_p, [_E]),
     "g2048_episode_stats": (C.c_int, [_E, C.POINTER(Stats), _S]),
     "g2048_set_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),

@@ -271,10 +271,20 @@ class Batched2048:
         check(self._lib.g2048_get_scores(self._h, out.data_ptr(), self._stream()))
         return out
 
-    def last_scores(self) -> torch.Tensor:
-        """Zero-copy ``int32 [n]``: final score of each board's most recently finished episode."""
-        ptr = self._lib.g2048_last_score_ptr(self._h)
-        return torch.as_tensor(_DeviceView(ptr, (self.n_envs,), "<i4"), device=self.device)
+    def last_scores(self, out=None) -> torch.Tensor:
+        """``int32 [n]`` on the device: final score of each board's most recently finished episode (0 before
+        the first one), computed from the stored terminal records."""
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        if out.dtype != torch.int32 or tuple(out.shape) != (self.n_envs,) or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous int32 [n] tensor on the engine's device")
+        check(self._lib.g2048_get_last_scores(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def last_records(self) -> torch.Tensor:
+        """Zero-copy ``uint8 [n, 16]``: the record each board's most recent episode ended on (all-zero: none)."""
+        ptr = self._lib.g2048_last_records_ptr(self._h)
+        return torch.as_tensor(_DeviceView(ptr, (self.n_envs, 16), "|u1"), device=self.device)
 
     def tile_values(self) -> torch.Tensor:
         """int64 ``[n, 4, 4]`` tile values as the reference holds them (game2048_env.py:104)."""
@@ -336,12 +346,13 @@ class Batched2048:
         return buf
 
     def episode_stats(self) -> dict:
-        """Aggregate over all episodes finished since create/seed (reduced on the device)."""
+        """Episode statistics since create/seed, reduced on the device: ``episodes`` / ``illegal_ends`` count
+        every finished episode; ``last_*`` describe each board's most recent finished episode."""
         st = Stats()
         check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
-        return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, score_sum=st.score_sum,
-                    max_score=st.max_score, max_exp=st.max_exp,
-                    mean_score=(st.score_sum / st.episodes) if st.episodes else 0.0,
+        return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count,
+                    last_score_sum=st.last_score_sum, last_score_max=st.last_score_max, max_exp=st.max_exp,
+                    mean_last_score=(st.last_score_sum / st.last_count) if st.last_count else 0.0,
                     highest_hist=[int(x) for x in st.highest_hist])
 
     # ------------------------------------------------------------------ checkpoint / resume

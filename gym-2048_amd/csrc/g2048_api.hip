@@ -145,11 +145,11 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
 
     const size_t n = n_boards;
     const size_t off_boards = 0;
-    const size_t off_last_score = off_boards + align_up(n * 16);
-    const size_t off_wave_stats = off_last_score + align_up(n * 4);
-    // one slot per 64 boards, rounded up to whole 1024-lane blocks
-    const size_t n_slots = ((n + 1023) / 1024) * 16;
-    const size_t off_stats = off_wave_stats + align_up(n_slots * sizeof(g2048::WaveStats));
+    const size_t off_last_record = off_boards + align_up(n * 16);
+    const size_t off_counters = off_last_record + align_up(n * 16);
+    // two counters per 64 boards (whole 256-lane launch blocks)
+    const size_t n_counters = ((n + 255) / 256) * 8;
+    const size_t off_stats = off_counters + align_up(n_counters * sizeof(unsigned long long));
     e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
     err = hipMalloc(&e->slab, e->slab_bytes);
     if (err != hipSuccess) {
@@ -165,8 +165,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     }
     char *base = static_cast<char *>(e->slab);
     e->st.boards = reinterpret_cast<uint4 *>(base + off_boards);
-    e->st.last_score = reinterpret_cast<int32_t *>(base + off_last_score);
-    e->st.wave_stats = reinterpret_cast<g2048::WaveStats *>(base + off_wave_stats);
+    e->st.last_record = reinterpret_cast<uint4 *>(base + off_last_record);
+    e->st.ep_counters = reinterpret_cast<unsigned long long *>(base + off_counters);
     e->stats_dev = reinterpret_cast<g2048::StatsOut *>(base + off_stats);
     *out = e;
     return G2048_OK;
@@ -537,13 +537,26 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
     return G2048_OK;
 }
 
-int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream)
+int g2048_get_last_scores(const g2048_engine *ce, int32_t *buf, void *stream)
 {
-    return copy_out(e, buf, e ? e->st.last_score : nullptr, e ? e->n * 4 : 0, stream);
+    g2048_engine *e = const_cast<g2048_engine *>(ce);
+    if (!e || !buf)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n = static_cast<uint32_t>(e->n);
+    if (is_device_ptr(buf)) {
+        G2048_HIP(g2048::launch_export_last_scores(e->st, n, buf, s));
+        return G2048_OK; // device destination: ready in stream order
+    }
+    if (int rc = ensure_scratch(e))
+        return rc;
+    G2048_HIP(g2048::launch_export_last_scores(e->st, n, static_cast<int32_t *>(e->scratch), s));
+    return copy_out(e, buf, e->scratch, e->n * 4, stream);
 }
 
 void *g2048_records_ptr(const g2048_engine *e) { return e ? e->st.boards : nullptr; }
-void *g2048_last_score_ptr(const g2048_engine *e) { return e ? e->st.last_score : nullptr; }
+void *g2048_last_records_ptr(const g2048_engine *e) { return e ? e->st.last_record : nullptr; }
 
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
 {
@@ -557,8 +570,9 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     G2048_HIP(hipStreamSynchronize(s));
     out->episodes = h.episodes;
     out->illegal_ends = h.illegal_ends;
-    out->score_sum = static_cast<int64_t>(h.score_sum);
-    out->max_score = h.max_score;
+    out->last_count = h.last_count;
+    out->last_score_sum = static_cast<int64_t>(h.last_score_sum);
+    out->last_score_max = h.last_score_max;
     out->max_exp = h.max_exp;
     for (int k = 0; k < 32; ++k)
         out->highest_hist[k] = h.highest_hist[k];
@@ -810,15 +824,22 @@ int g2048_comm_destroy(g2048_comm *c)
     return G2048_OK;
 }
 
-int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, void *stream)
+int g2048_allgather_returns(const g2048_engine *ce, g2048_comm *c, int32_t *out, void *stream)
 {
+    g2048_engine *e = const_cast<g2048_engine *>(ce);
     if (!e || !c || !out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (c->device != e->device)
         return fail(G2048_ERR_INVALID, "communicator is on device %d, engine on device %d", c->device, e->device);
     G2048_HIP(hipSetDevice(e->device));
-    // equal shards: rank r's n returns land at out[r * n]
-    G2048_NCCL(g_rccl.AllGather(e->st.last_score, out, e->n, ncclInt32, c->comm, static_cast<hipStream_t>(stream)));
+    if (int rc = ensure_scratch(e))
+        return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the returns are the scores of last_record: materialise int32[n] in the staging buffer, then ONE
+    // all-gather (equal shards: rank r's n returns land at out[r * n]), all on the caller's stream
+    int32_t *send = static_cast<int32_t *>(e->scratch);
+    G2048_HIP(g2048::launch_export_last_scores(e->st, static_cast<uint32_t>(e->n), send, s));
+    G2048_NCCL(g_rccl.AllGather(send, out, e->n, ncclInt32, c->comm, s));
     return G2048_OK;
 }
 
@@ -839,8 +860,15 @@ int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, i
         return rc;
     int devs[64];
     ncclComm_t comms[64];
-    for (int r = 0; r < n_engines; ++r)
+    for (int r = 0; r < n_engines; ++r) {
         devs[r] = engines[r]->device;
+        G2048_HIP(hipSetDevice(devs[r]));
+        if (int rc = ensure_scratch(engines[r]))
+            return rc;
+        G2048_HIP(g2048::launch_export_last_scores(engines[r]->st, static_cast<uint32_t>(engines[r]->n),
+                                                   static_cast<int32_t *>(engines[r]->scratch),
+                                                   static_cast<hipStream_t>(streams ? streams[r] : nullptr)));
+    }
     G2048_NCCL(g_rccl.CommInitAll(comms, n_engines, devs)); // single process, one communicator per device
     int rc = G2048_OK;
     ncclResult_t res = g_rccl.GroupStart();
@@ -849,7 +877,7 @@ int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, i
             res = ncclUnhandledCudaError;
             break;
         }
-        res = g_rccl.AllGather(engines[r]->st.last_score, outs[r], engines[r]->n, ncclInt32, comms[r],
+        res = g_rccl.AllGather(engines[r]->scratch, outs[r], engines[r]->n, ncclInt32, comms[r],
                                static_cast<hipStream_t>(streams ? streams[r] : nullptr));
     }
     const ncclResult_t end = g_rccl.GroupEnd();

@@ -422,6 +422,76 @@ G2048_DEV Board fresh_record(uint32_t w1, uint32_t w2)
     return bd;
 }
 
+// The same through a 16-entry table of one-tile boards (entry p = a board whose only tile is a 2,
+// exponent 1, in cell p): two table reads, shifts and ORs instead of ~40 VALU of placement logic.
+// `Tables` supplies onehot_cell(p) (LDS on the device, an array in the host check).
+template <class Tables>
+G2048_DEV Board fresh_record_lut(uint32_t w1, uint32_t w2, const Tables &tb)
+{
+    const uint32_t p1 = w1 >> 28;                  // (w1 * 16) >> 32: cell of the first tile
+    const uint32_t k2 = g2048_mulhi(w2, 15u);
+    const uint32_t p2 = k2 + (k2 >= p1 ? 1u : 0u); // k2-th empty cell, skipping p1
+    const uint32_t s1 = ((w1 & 0xffffu) > 58982u) ? 1u : 0u; // 1: the tile is a 4 (exponent 2 = 1 << 1)
+    const uint32_t s2 = ((w2 & 0xffffu) > 58982u) ? 1u : 0u;
+    const Board a = tb.onehot_cell(p1), b = tb.onehot_cell(p2);
+    const uint32_t fours = s1 + s2;
+    Board bd;
+    bd.r[0] = (a.r[0] << s1) | (b.r[0] << s2);
+    bd.r[1] = (a.r[1] << s1) | (b.r[1] << s2);
+    bd.r[2] = (a.r[2] << s1) | (b.r[2] << s2) | ((fours & 1u) << 7) | ((fours >> 1) << 13); // d = 4 * fours
+    bd.r[3] = (a.r[3] << s1) | (b.r[3] << s2);
+    return bd;
+}
+
+// word j (0..3) of entry p of the one-tile table: 1 in byte p & 3 of register p >> 2
+G2048_DEV uint32_t onehot_cell_word(uint32_t p, uint32_t j) { return (p >> 2) == j ? 1u << (8u * (p & 3u)) : 0u; }
+
+// ---------------------------------------------------------------------- one env step on a record
+struct StepOut {
+    uint32_t gain;   // merge score of the move (:85); 0 when illegal
+    bool legal;      // false = the reference's IllegalMove (:91)
+    bool terminated; // :89 / :94
+    Board terminal;  // record after move + spawn, before any auto-reset (valid always; "terminal" when terminated)
+};
+
+// game2048_env.py:76-100 on one board RECORD, followed -- when auto_reset -- by the caller's
+// `if terminated: env.reset()` (:102-111).  w = Philox block of this transaction: word 0 = the step's
+// spawn; the reset uses words 1,2 after a legal move and 0,1 after an illegal one (an illegal move
+// consumes no randomness, :91-95).  The score never appears: a merge moves potential and score together,
+// only a spawned 4 touches the deficit.
+template <class Tables>
+G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint32_t max_exp, bool auto_reset,
+                              const Tables &tb)
+{
+    StepOut o;
+    Board cells = record_cells(rec);
+    o.legal = move_sel(cells, tb.move_sel(action), o.gain);        // :85 (illegal: board unchanged, gain 0)
+    // :88 add_tile needs an empty cell; a board that changed always has one (a full board can only
+    // change by merging).  After an illegal move nothing is spawned (:91-95).
+    const uint32_t n_empty = add_tile(cells, w.w[0], lanemask(o.legal));
+    // :89 isend(): the board is full after the spawn exactly when it had one empty cell before it
+    bool end = false;
+    if (n_empty == 1u)                                             // :270-271
+        end = !has_equal_neighbours(cells);                        // :273-280
+    if (max_exp != 0 && highest(cells) == max_exp)                 // :267-268
+        end = true;
+    o.terminated = o.legal ? end : true;                           // :89, :94
+    // a spawned 4 raises the potential without scoring: deficit += 4 (bit 2 of d = bit 7 of byte 8)
+    const uint32_t inc = (o.legal && (w.w[0] & 0xffffu) > 58982u) ? 0x80u : 0u;
+    record_update(rec, cells, inc);
+    o.terminal = rec;
+    const bool do_reset = o.terminated && auto_reset;
+    if (g2048_any(do_reset)) {                                     // wave-uniform: skipped when nobody finished
+        const uint32_t lm = lanemask(o.legal), rm = lanemask(do_reset);
+        const Board fb = fresh_record_lut(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]), tb); // :104-109
+        rec.r[0] = bfi(rm, fb.r[0], rec.r[0]);
+        rec.r[1] = bfi(rm, fb.r[1], rec.r[1]);
+        rec.r[2] = bfi(rm, fb.r[2], rec.r[2]);
+        rec.r[3] = bfi(rm, fb.r[3], rec.r[3]);
+    }
+    return o;
+}
+
 // ------------------------------------------------------------------------------ one env step
 struct StepResult {
     float reward;

@@ -7,26 +7,16 @@
 
 namespace g2048 {
 
-// Episode accumulators: the only episode bookkeeping the step kernels touch besides last_score.
-// One slot per 64 boards.  step_kernel uses the FIRST slot of each thread block (updated once per
-// launch by the block's fixer wave, plain load-add-store by one lane); the fused rollout kernels use
-// the slot of each wavefront.  stats_kernel sums all slots.
-struct alignas(8) WaveStats {
-    unsigned int episodes;        // finished episodes
-    unsigned int illegal_ends;    // ... of which ended on an illegal move
-    unsigned long long score_sum; // sum of final merge scores
-    int max_score;
-    int pad;
-};
-
 // Engine-owned device state (one slab).
 struct DeviceState {
-    uint4 *boards;         // [n]   16-byte board RECORDS: 16 x 5-bit exponents + the 24-bit score deficit in
-                           //       the spare bits of bytes 8..15 (g2048_device.h "board RECORD"); there is no
-                           //       separate score array -- self.score (game2048_env.py:86) = potential - deficit
-    int32_t *last_score;   // [n]   final score of the board's last finished episode (write-only here)
-    WaveStats *wave_stats; // one per wavefront of the launch grid
-    uint64_t *rng;         // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
+    uint4 *boards;      // [n] 16-byte board RECORDS: 16 x 5-bit exponents + the 24-bit score deficit in the spare
+                        //     bits of bytes 8..15 (g2048_device.h "board RECORD"); there is no separate score
+                        //     array -- self.score (game2048_env.py:86) = potential - deficit
+    uint4 *last_record; // [n] record a board's most recent episode ENDED on (all-zero: none yet); its score is
+                        //     that episode's return.  Written only by lanes whose episode ended.
+    unsigned long long *ep_counters; // two per 64 boards: {finished episodes, of which ended on an illegal move},
+                                     // bumped with 64-bit atomics by ONE lane of a wavefront that finished episodes
+    uint64_t *rng;      // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
 };
 
 struct StepArgs {
@@ -48,10 +38,11 @@ struct StepArgs {
 };
 
 struct StatsOut {
-    unsigned long long episodes;
+    unsigned long long episodes;      // all finished episodes since create / seed
     unsigned long long illegal_ends;
-    unsigned long long score_sum;
-    int max_score;
+    unsigned long long last_count;    // boards that have finished at least one episode
+    unsigned long long last_score_sum; // sum / max of those boards' most recent final scores
+    int last_score_max;
     unsigned int max_exp;
     unsigned int highest_hist[32]; // boards whose highest tile is 2^k right now (game2048_env.py:190-192)
 };
@@ -79,9 +70,10 @@ hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hi
 // record <-> plain views (cells uint8[n][16], scores int32[n]); device pointers
 hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s);
 hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s);
-hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *scores_out, hipStream_t s);
+hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *scores_out, hipStream_t s); // also last_record -> returns
 hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, hipStream_t s);
 hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s);
+hipError_t launch_export_last_scores(const DeviceState &st, uint32_t n, int32_t *out, hipStream_t s);
 hipError_t launch_canonicalize(uint4 *boards, uint4 *next_boards, uint8_t *actions, uint32_t n, uint8_t *sym_out,
                                hipStream_t s);
 

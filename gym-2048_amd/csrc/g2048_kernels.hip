@@ -9,11 +9,9 @@
 // HBM bytes per env-step of step_kernel (the roofline figure in DESIGN.md):
 //   algorithmic 38 B = board in 16 + action 1 + board out 16 + reward 4 + terminated 1
 // and that is also all a step moves for a board whose episode goes on: the episodic score travels
-// inside the 16-byte record (g2048_device.h "board RECORD").  Boards whose episode ENDS (about 7 % of
-// the steps under a random policy) are handed through LDS to one "fixer" wavefront per thread block,
-// which scores them, writes last_score, installs the fresh board of the auto-reset and updates the
-// block's episode counters -- so the 93 % do not execute the reset / bookkeeping code at all (with one
-// board per lane a wavefront would otherwise run it in 99 % of the launches).
+// inside the 16-byte record (g2048_device.h "board RECORD").  A board whose episode ENDS additionally
+// writes its terminal record to last_record (sparse 16-byte store; the episode's return is computed
+// from it when somebody asks), and a wavefront that finished episodes bumps two counters.
 #include "g2048_kernels.h"
 
 #include "g2048_device.h"
@@ -22,8 +20,7 @@
 
 namespace g2048 {
 
-constexpr int kBlock = 256;     // utility kernels
-constexpr int kStepBlock = 512; // step_kernel: 8 wavefronts share one fixer
+constexpr int kBlock = 256;
 
 // Streaming accesses of the step kernels carry the non-temporal hint (nt=1): every byte is touched
 // exactly once per launch, so it should not displace anything in L2 / Infinity Cache.  Measured on
@@ -54,10 +51,16 @@ __device__ __forceinline__ void store_board(uint4 *boards, uint32_t i, const Boa
     boards[i] = make_uint4(b.r[0], b.r[1], b.r[2], b.r[3]);
 }
 
-// The per-action selector rows of move_sel (g2048_device.h), staged into LDS by the first 32 lanes
-// of a block; a lane then fetches its row with two ds_read_b128 (no VALU work, no bank conflicts:
-// four distinct 32-byte rows).
+// Per-WAVEFRONT lookup tables in LDS (384 B): the per-action selector rows of move_sel and the 16
+// one-tile boards of fresh_record_lut (g2048_device.h).  Each wavefront stages its own copy -- lanes
+// 0..31 fetch one selector word each (global load, L2-resident), every lane computes one word of the
+// one-tile table -- and only reads what it wrote itself, so no workgroup barrier is involved.
 __device__ const uint32_t kMoveLut[32] = {G2048_MOVE_LUT_WORDS};
+
+struct WaveTables {
+    uint32_t move[32]; // 4 actions x 8 words (6 used)
+    uint32_t cell[64]; // 16 cells x 4 words
+};
 
 // `x`, but not before `dep` has been computed (pins the s_waitcnt of a load below independent work).
 __device__ __forceinline__ uint32_t use_after(uint32_t x, uint32_t dep)
@@ -66,20 +69,36 @@ __device__ __forceinline__ uint32_t use_after(uint32_t x, uint32_t dep)
     return x;
 }
 
-// Two halves so that the global load is issued with the board load and its result is only waited
-// for just before the barrier (after the Philox block).
-__device__ __forceinline__ uint32_t load_move_lut_word() { return threadIdx.x < 32u ? kMoveLut[threadIdx.x] : 0u; }
+struct LdsTables {
+    const WaveTables *t;
+    __device__ __forceinline__ MoveSel move_sel(uint32_t action) const
+    {
+        const uint4 a = *reinterpret_cast<const uint4 *>(t->move + action * 8u);
+        const uint2 b = *reinterpret_cast<const uint2 *>(t->move + action * 8u + 4u);
+        return MoveSel{a.x, a.y, a.z, a.w, b.x, b.y};
+    }
+    __device__ __forceinline__ Board onehot_cell(uint32_t p) const
+    {
+        const uint4 v = *reinterpret_cast<const uint4 *>(t->cell + p * 4u);
+        return Board{{v.x, v.y, v.z, v.w}};
+    }
+};
 
-__device__ __forceinline__ void stage_move_lut(uint4 *s_lut, uint32_t word)
-{
-    if (threadIdx.x < 32u)
-        reinterpret_cast<uint32_t *>(s_lut)[threadIdx.x] = word;
-}
+// Two halves so that the global load is issued early and waited for late (after the Philox block).
+__device__ __forceinline__ uint32_t load_move_lut_word() { return kMoveLut[threadIdx.x & 31u]; }
 
-__device__ __forceinline__ MoveSel fetch_move_sel(const uint4 *s_lut, uint32_t action)
+__device__ __forceinline__ LdsTables stage_tables(WaveTables *all, uint32_t lut_word)
 {
-    const uint4 a = s_lut[action * 2u], b = s_lut[action * 2u + 1u];
-    return MoveSel{a.x, a.y, a.z, a.w, b.x, b.y};
+    const uint32_t lane = threadIdx.x & 63u;
+    WaveTables *t = all + (threadIdx.x >> 6);
+    if (lane < 32u)
+        t->move[lane] = lut_word;
+    t->cell[lane] = onehot_cell_word(lane >> 2, lane & 3u);
+    // same-wave LDS writes are visible to the wave's later reads in program order; the fence only
+    // keeps the compiler from moving those reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return LdsTables{t};
 }
 
 template <int ACT>
@@ -95,336 +114,144 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
         return static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(actions) + i)) & 3u;
 }
 
-// Wave-wide sum and max of a non-negative per-lane value, result valid in lane 63.  Seven DPP steps
-// each (row_shr 1,2,3,4,8 then row_bcast 15, 31): pure VALU, no LDS, no scalar loop.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ int dpp_shift(int v)
+// Episode bookkeeping, shared by every step kernel.  A lane whose episode ended stores the record it
+// ended on (sparse 16-byte store; plain, not nt: L2 merges these into lines) and, if asked, the plain
+// terminal board; ONE lane of the wavefront then adds the wave's two counts with 64-bit atomics to the
+// wave's own counter pair (distinct addresses per wavefront: no contention).  Skipped entirely by a
+// wave-uniform branch when no lane terminated.
+__device__ __forceinline__ void record_episode_ends(const StepArgs &p, uint32_t i, bool fin, bool illegal, const Board &terminal,
+                                                    uint32_t &episodes, uint32_t &illegal_ends)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
-}
-
-__device__ __forceinline__ int wave_sum(int v) // result in lane 63
-{
-    int s = v + dpp_shift<0x111, 0xf, 0xf>(v) + dpp_shift<0x112, 0xf, 0xf>(v) + dpp_shift<0x113, 0xf, 0xf>(v);
-    s += dpp_shift<0x114, 0xf, 0xe>(s);
-    s += dpp_shift<0x118, 0xf, 0xc>(s);
-    s += dpp_shift<0x142, 0xa, 0xf>(s); // row_bcast:15 into rows 1 and 3
-    s += dpp_shift<0x143, 0xc, 0xf>(s); // row_bcast:31 into rows 2 and 3
-    return s;
-}
-
-__device__ __forceinline__ int wave_max(int v) // non-negative v; result broadcast to the whole wave
-{
-    int m = max(max(v, dpp_shift<0x111, 0xf, 0xf>(v)), max(dpp_shift<0x112, 0xf, 0xf>(v), dpp_shift<0x113, 0xf, 0xf>(v)));
-    m = max(m, dpp_shift<0x114, 0xf, 0xe>(m));
-    m = max(m, dpp_shift<0x118, 0xf, 0xc>(m));
-    m = max(m, dpp_shift<0x142, 0xa, 0xf>(m));
-    m = max(m, dpp_shift<0x143, 0xc, 0xf>(m));
-    return __builtin_amdgcn_readlane(m, 63);
-}
-
-// Episode bookkeeping of the FUSED rollout kernels (the per-step kernel hands finished episodes to
-// its block fixer instead).  Boards that ended an episode write their final score; the wave's totals
-// are accumulated in lane 63.  The whole block is skipped by a wave-uniform branch when no lane
-// terminated.
-struct WaveAcc {
-    unsigned int episodes = 0, illegal_ends = 0;
-    unsigned long long score_sum = 0; // valid in lane 63 only
-    int max_score = 0;                // wave-uniform
-};
-
-// `best_so_far`: the wave's recorded best final score (uniform).  The max reduction only runs when
-// some lane beats it, which after the first few hundred episodes of a wave practically never happens.
-__device__ __forceinline__ void record_episodes(const StepArgs &p, uint32_t i, const StepResult &r, WaveAcc &acc,
-                                                int best_so_far)
-{
-    const unsigned long long done = __ballot(r.terminated);
-    if (done == 0)
+    const unsigned long long done = __ballot(fin);
+    if (done == 0ull)
         return;
-    // plain (cached) stores on purpose: these are sparse 4/16-byte writes, which L2 merges into
-    // lines; with the nt hint they cost 12 % of the launch at 2^24 boards
-    if (r.terminated) {
-        p.st.last_score[i] = r.terminal_score;
+    if (fin) {
+        store_board(p.st.last_record, i, terminal);
         if (p.terminal_boards)
-            p.terminal_boards[i] = make_uint4(r.terminal.r[0], r.terminal.r[1], r.terminal.r[2], r.terminal.r[3]);
+            store_board(p.terminal_boards, i, record_cells(terminal));
     }
-    acc.episodes += static_cast<unsigned int>(__popcll(done));
-    acc.illegal_ends += static_cast<unsigned int>(__popcll(__ballot(r.terminated && r.illegal)));
-    const int v = r.terminated ? r.terminal_score : 0;
-    acc.score_sum += static_cast<unsigned long long>(static_cast<long long>(wave_sum(v)));
-    if (__ballot(v > max(best_so_far, acc.max_score)) != 0ull)
-        acc.max_score = max(acc.max_score, wave_max(v));
+    episodes += static_cast<uint32_t>(__popcll(done));
+    illegal_ends += static_cast<uint32_t>(__popcll(__ballot(fin && illegal)));
 }
 
-// The wave's slot is private to it (one wave per slot per launch, launches are stream-ordered), so
-// the accumulators are updated with a plain load-add-store by ONE lane (63, where the DPP
-// reductions land).  Requires full wavefronts: the launchers pad the tail wave's bookkeeping by
-// running it with all 64 lanes active (boards beyond n are never touched).
-__device__ __forceinline__ void flush_wave_stats(WaveStats *slot, const WaveStats &old, const WaveAcc &acc)
+__device__ __forceinline__ void flush_episode_counts(const StepArgs &p, uint32_t i_raw, uint32_t episodes, uint32_t illegal_ends)
 {
-    if (acc.episodes == 0 || (threadIdx.x & 63u) != 63u)
+    if (episodes == 0u || (threadIdx.x & 63u) != 0u) // episodes is wave-uniform
         return;
-    WaveStats ws;
-    ws.episodes = old.episodes + acc.episodes;
-    ws.illegal_ends = old.illegal_ends + acc.illegal_ends;
-    ws.score_sum = old.score_sum + acc.score_sum;
-    ws.max_score = max(old.max_score, acc.max_score);
-    ws.pad = 0;
-    *slot = ws;
+    unsigned long long *c = p.st.ep_counters + 2u * (i_raw >> 6);
+    __hip_atomic_fetch_add(c, static_cast<unsigned long long>(episodes), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (illegal_ends != 0u)
+        __hip_atomic_fetch_add(c + 1, static_cast<unsigned long long>(illegal_ends), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
-// Per lane: load the 16-byte record + the action -> Philox block (independent of the loads, so it
-// runs while they are in flight) -> move through the lane's selector row (LDS) -> spawn -> done
-// detection -> deficit update -> store record, reward, terminated.  A lane whose episode ended
-// instead appends (terminal record, the two reset spawn words, flags) to its wave's list in LDS.
-// The LAST wavefront of the block to get that far (an LDS arrival counter, no barrier: the other
-// waves retire at once) becomes the block's FIXER: one lane per finished episode computes the
-// final score (potential - deficit), writes last_score, stores the fresh record of the auto-reset
-// (game2048_env.py:102-111) and folds count / illegal ends / score sum / best score into the block's
-// WaveStats slot.
-//
-// LDS per block: selector table 128 B + 2 x 16 B per lane (worst case: every board ends).
-template <int BLOCK>
-struct StepShared {
-    uint4 lut[8];
-    uint4 rec[BLOCK]; // terminal records, wave w's list starts at w * 64
-    uint4 aux[BLOCK]; // {reset spawn word 1, word 2, lane-in-block | do_reset << 30 | illegal << 31, -}
-    uint32_t count[BLOCK / 64];
-    uint32_t arrived;
-};
-
-template <int BLOCK>
-__device__ __forceinline__ void run_fixer(const StepArgs &p, StepShared<BLOCK> &sh)
+// One board per lane, one pass: load the 16-byte record + the action -> Philox block (independent of
+// the loads, so it runs while they are in flight) -> step_record (move through the lane's selector row,
+// spawn, done detection, deficit update, auto-reset through the one-tile table) -> store record, reward,
+// terminated.  No barrier, no cross-wave traffic.
+template <int ACT>
+__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
 {
-    constexpr int WAVES = BLOCK / 64;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t total = 0;
-    uint32_t pre[WAVES + 1];
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        pre[w] = total;
-        total += __builtin_amdgcn_readfirstlane(sh.count[w]); // wave-uniform: keeps the loop scalar
-    }
-    pre[WAVES] = total;
-    if (total == 0)
-        return;
-    WaveStats *slot = p.st.wave_stats + ((blockIdx.x * BLOCK) >> 6);
-    const WaveStats old = *slot; // same address in every lane: one request, in flight during the scoring
-    unsigned int illegal_ends = 0;
-    long long score_sum = 0;
-    int best = 0;
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t j = base + lane;
-        const bool on = j < total;
-        uint32_t wv = 0, start = 0;
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            if (j >= pre[w]) {
-                wv = w;
-                start = pre[w];
-            }
-        }
-        const uint32_t e = on ? wv * 64u + (j - start) : 0u;
-        const uint4 rv = sh.rec[e], av = sh.aux[e];
-        const Board term{{rv.x, rv.y, rv.z, rv.w}};
-        const int score = on ? static_cast<int>(record_score(term)) : 0; // :86 self.score at the end
-        const uint32_t i = blockIdx.x * BLOCK + (av.z & 0xffffu);
-        if (on) {
-            // plain (cached) stores: sparse writes that L2 merges into lines
-            p.st.last_score[i] = score;
-            if (av.z & 0x40000000u)
-                store_board(p.st.boards, i, fresh_record(av.x, av.y)); // :102-111
-        }
-        illegal_ends += static_cast<unsigned int>(__popcll(__ballot(on && (av.z >> 31) != 0u)));
-        score_sum += static_cast<long long>(wave_sum(score));
-        if (__ballot(score > max(best, old.max_score)) != 0ull)
-            best = max(best, wave_max(score));
-    }
-    if (lane == 63u) {
-        WaveStats ws;
-        ws.episodes = old.episodes + total;
-        ws.illegal_ends = old.illegal_ends + illegal_ends;
-        ws.score_sum = old.score_sum + static_cast<unsigned long long>(score_sum);
-        ws.max_score = max(old.max_score, best);
-        ws.pad = 0;
-        *slot = ws;
-    }
-}
-
-enum { X_NOFIX = 1, X_OWNERSTORE = 2, X_NOLUT = 4, X_NOBARRIER = 8 }; // experiment switches (tools/ubench/step_v2.hip)
-
-template <int ACT, int BLOCK, int X = 0>
-__global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs p)
-{
-    constexpr int WAVES = BLOCK / 64;
-    static_assert(BLOCK >= 128 && BLOCK % 64 == 0, "step_kernel needs at least two wavefronts per block");
-    __shared__ StepShared<BLOCK> sh;
-    // Lanes past the end stay active (barrier, DPP reductions of the fixer): they recompute board
-    // n-1 and write nothing.
-    const uint32_t tid = threadIdx.x;
-    const uint32_t i_raw = blockIdx.x * BLOCK + tid;
-    const bool valid = i_raw < p.n;
-    const uint32_t i = valid ? i_raw : p.n - 1u;
-    const Board raw = load_board_nt(p.st.boards, i);
-    const uint32_t lut_word = (X & X_NOLUT) ? 0u : load_move_lut_word();
-    if (tid >= 64u && tid < 64u + WAVES)
-        sh.count[tid - 64u] = 0u;
-    if (tid == 64u + WAVES)
-        sh.arrived = 0u;
-
-    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
-    const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
-    if (!(X & X_NOLUT))
-        stage_move_lut(sh.lut, use_after(lut_word, w.w[0])); // the wait for the table word sits after the Philox block
-    if (!(X & X_NOBARRIER))
-        __syncthreads(); // selector table + counters visible; every wave is waiting for its loads anyway
-
-    Board cells = record_cells(raw);
-    uint32_t gain;
-    bool legal;
-    if (X & X_NOLUT) {
-        legal = move(cells, action, gain);
-    } else {
-        const MoveSel sel = fetch_move_sel(sh.lut, action);
-        legal = move_sel(cells, sel, gain);                        // :85 (illegal: board unchanged, gain 0)
-    }
-    // :88 add_tile needs an empty cell; a board that changed always has one.  After an illegal move
-    // nothing is spawned (:91-95).
-    const uint32_t n_empty = add_tile(cells, w.w[0], lanemask(legal));
-    // :89 isend(): the board is full after the spawn exactly when it had one empty cell before it
-    bool end = false;
-    if (n_empty == 1u)                                             // :270-271
-        end = !has_equal_neighbours(cells);                        // :273-280
-    if (p.max_exp != 0 && highest(cells) == p.max_exp)             // :267-268
-        end = true;
-    const bool terminated = legal ? end : true;                    // :89, :94
-    // a spawned 4 raises the potential without scoring: deficit += 4 (bit 2 of d = bit 7 of byte 8)
-    const uint32_t inc = (legal && (w.w[0] & 0xffffu) > 58982u) ? 0x80u : 0u;
-    Board out = raw;
-    record_update(out, cells, inc);
-    const bool do_reset = terminated && p.auto_reset != 0;
-
-    if (valid) {
-        if (!do_reset || (X & (X_OWNERSTORE | X_NOFIX)))
-            store_board_nt(p.st.boards, i, out);
-        if (p.reward)                                              // :90 / :95
-            __builtin_nontemporal_store(legal ? static_cast<float>(gain) : p.illegal_reward, p.reward + i);
-        if (p.terminated)
-            __builtin_nontemporal_store(static_cast<uint8_t>(terminated ? 1 : 0), p.terminated + i);
-        if (p.illegal)
-            __builtin_nontemporal_store(static_cast<uint8_t>(legal ? 0 : 1), p.illegal + i);
-        if (p.highest)
-            __builtin_nontemporal_store(static_cast<uint8_t>(highest(cells)), p.highest + i); // :97
-        if (terminated && p.terminal_boards)
-            p.terminal_boards[i] = make_uint4(cells.r[0], cells.r[1], cells.r[2], cells.r[3]);
-    }
-
-    if (X & X_NOFIX)
-        return;
-    // ---- finished episodes -> this wave's list in LDS
-    const bool fin = terminated && valid;
-    const unsigned long long fin_mask = __ballot(fin);
-    const uint32_t wave = tid >> 6;
-    if (fin_mask != 0ull) {
-        if (fin) {
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fin_mask >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fin_mask), 0u));
-            const uint32_t e = wave * 64u + below;
-            const uint32_t lm = lanemask(legal);
-            // the reset uses words 1,2 after a legal move and 0,1 after an illegal one (:91-95)
-            sh.rec[e] = make_uint4(out.r[0], out.r[1], out.r[2], out.r[3]);
-            sh.aux[e] = make_uint4(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]),
-                                   tid | (do_reset ? 0x40000000u : 0u) | (legal ? 0u : 0x80000000u), 0u);
-        }
-        sh.count[wave] = static_cast<uint32_t>(__popcll(fin_mask)); // same value from every lane
-    }
-    // ---- arrival: the last wave of the block becomes the fixer (release/acquire at workgroup scope
-    //      orders the LDS lists against the counter)
-    uint32_t arrived = 0;
-    if ((tid & 63u) == 0u)
-        arrived = __hip_atomic_fetch_add(&sh.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-    arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if (arrived != WAVES - 1)
-        return;
-    run_fixer<BLOCK>(p, sh);
-}
-
-// ------------------------------------------------------------------------- fused rollout
-// k steps of the synthetic random policy in ONE launch; the board never leaves registers.  The record
-// is unpacked to (cells, score) once and packed once.
-__global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p)
-{
+    __shared__ WaveTables s_tables[kBlock / 64];
+    // Lanes past the end stay active (whole wavefronts for the ballots): they recompute board n-1
+    // and write nothing.
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    const Board raw = load_board(p.st.boards, i);
-    Board bd = record_cells(raw);
-    int32_t score = static_cast<int32_t>(record_score(raw));
+    Board rec = load_board_nt(p.st.boards, i);
+    const uint32_t lut_word = load_move_lut_word();
+
+    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+    const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
+    const LdsTables tb = stage_tables(s_tables, use_after(lut_word, w.w[0]));
+
+    const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
+
+    if (valid) {
+        store_board_nt(p.st.boards, i, rec);
+        if (p.reward)                                              // :90 / :95
+            __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + i);
+        if (p.terminated)
+            __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
+        if (p.illegal)
+            __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + i);
+        if (p.highest)
+            __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(o.terminal))), p.highest + i); // :97
+    }
+    uint32_t episodes = 0, illegal_ends = 0;
+    record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
+    flush_episode_counts(p, i_raw, episodes, illegal_ends);
+}
+
+// ------------------------------------------------------------------------- fused rollout
+// k steps of the synthetic random policy in ONE launch; the record never leaves registers.
+__global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p)
+{
+    __shared__ WaveTables s_tables[kBlock / 64];
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
+    Board rec = load_board(p.st.boards, i);
+    const LdsTables tb = stage_tables(s_tables, load_move_lut_word());
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
-    WaveAcc acc;
+    uint32_t episodes = 0, illegal_ends = 0;
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
                                       p.seed_lo, p.seed_hi);
-        StepResult r = step_env(bd, score, w.w[3] >> 30, w, p.illegal_reward, p.max_exp, true);
-        r.terminated = r.terminated && valid;
-        record_episodes(p, i, r, acc, 0);
+        const StepOut o = step_record(rec, w.w[3] >> 30, w, p.max_exp, true, tb);
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
     }
     if (valid)
-        store_board(p.st.boards, i, make_record(bd, static_cast<uint32_t>(score)));
-    WaveStats *slot = p.st.wave_stats + (i_raw >> 6);
-    flush_wave_stats(slot, *slot, acc);
+        store_board(p.st.boards, i, rec);
+    flush_episode_counts(p, i_raw, episodes, illegal_ends);
 }
 
 // ---------------------------------------------------------------- fused rollout with per-step I/O
-// The same k steps g2048_rollout performs with k launches, in ONE launch: boards and scores stay in
+// The same k steps g2048_rollout performs with k launches, in ONE launch: the record stays in
 // registers, each step reads action[j][i] and writes reward[j][i] / terminated[j][i] (stride = elements
 // between consecutive steps).  Bit-identical outputs; 6 B of traffic per env-step instead of 38.
 template <int ACT>
 __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p, uint64_t stride)
 {
+    __shared__ WaveTables s_tables[kBlock / 64];
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    const Board raw = load_board_nt(p.st.boards, i);
-    Board bd = record_cells(raw);
-    int32_t score = static_cast<int32_t>(record_score(raw));
-    WaveStats *slot = p.st.wave_stats + (i_raw >> 6);
-    const WaveStats old_stats = *slot;
+    Board rec = load_board_nt(p.st.boards, i);
+    const LdsTables tb = stage_tables(s_tables, load_move_lut_word());
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
-    WaveAcc acc;
+    uint32_t episodes = 0, illegal_ends = 0;
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
-        const size_t o = static_cast<size_t>(j) * stride + i;
+        const size_t o_idx = static_cast<size_t>(j) * stride + i;
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
                                       p.seed_lo, p.seed_hi);
         uint32_t action;
         if constexpr (ACT == 0)
             action = w.w[3] >> 30;
         else if constexpr (ACT == 1)
-            action = __builtin_nontemporal_load(static_cast<const uint8_t *>(p.actions) + o) & 3u;
+            action = __builtin_nontemporal_load(static_cast<const uint8_t *>(p.actions) + o_idx) & 3u;
         else if constexpr (ACT == 2)
-            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(p.actions) + o)) & 3u;
+            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(p.actions) + o_idx)) & 3u;
         else
-            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(p.actions) + o)) & 3u;
-        StepResult r = step_env(bd, score, action, w, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(p.actions) + o_idx)) & 3u;
+        const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
         if (valid) {
             if (p.reward)
-                __builtin_nontemporal_store(r.reward, p.reward + o);
+                __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + o_idx);
             if (p.terminated)
-                __builtin_nontemporal_store(static_cast<uint8_t>(r.terminated ? 1 : 0), p.terminated + o);
+                __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + o_idx);
             if (p.illegal)
-                __builtin_nontemporal_store(static_cast<uint8_t>(r.illegal ? 1 : 0), p.illegal + o);
+                __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + o_idx);
             if (p.highest)
-                __builtin_nontemporal_store(static_cast<uint8_t>(highest(r.terminal)), p.highest + o);
+                __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(o.terminal))), p.highest + o_idx);
         }
-        r.terminated = r.terminated && valid;
-        record_episodes(p, i, r, acc, max(old_stats.max_score, acc.max_score));
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
     }
     if (valid)
-        store_board_nt(p.st.boards, i, make_record(bd, static_cast<uint32_t>(score)));
-    flush_wave_stats(slot, old_stats, acc);
+        store_board_nt(p.st.boards, i, rec);
+    flush_episode_counts(p, i_raw, episodes, illegal_ends);
 }
 
 // ------------------------------------------------------------------------- numpy-RNG mode
@@ -452,8 +279,6 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     Board bd = record_cells(raw);
     int32_t score = static_cast<int32_t>(record_score(raw));
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
-    WaveStats *slot = p.st.wave_stats + (i_raw >> 6);
-    const WaveStats old_stats = *slot;
     uint32_t action;
     if constexpr (ACT == 0)
         action = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi).w[3] >> 30;
@@ -474,10 +299,12 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
         if (p.highest)
             p.highest[i] = static_cast<uint8_t>(highest(r.terminal));
     }
-    r.terminated = r.terminated && valid;
-    WaveAcc acc;
-    record_episodes(p, i, r, acc, old_stats.max_score);
-    flush_wave_stats(slot, old_stats, acc);
+    uint32_t episodes = 0, illegal_ends = 0;
+    // (this mode carries the score unpacked; the terminal record is packed only where an episode ended)
+    const bool fin = r.terminated && valid;
+    const Board terminal = g2048_any(fin) ? make_record(r.terminal, static_cast<uint32_t>(r.terminal_score)) : r.terminal;
+    record_episode_ends(p, i, fin, r.illegal, terminal, episodes, illegal_ends);
+    flush_episode_counts(p, i_raw, episodes, illegal_ends);
 }
 
 // numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.
@@ -628,13 +455,22 @@ __global__ void __launch_bounds__(kBlock) import_scores_kernel(uint4 *records, u
     store_board(records, i, make_record(cells, static_cast<uint32_t>(scores_in[i]) & kScoreMask));
 }
 
-__global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState st, uint32_t n, uint32_t n_slots)
+// g2048_seed: forget the finished episodes (game2048_env.py:103 restarts the stream)
+__global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState st, uint32_t n, uint32_t n_counters)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n)
-        st.last_score[i] = 0;
-    if (i < n_slots)
-        st.wave_stats[i] = WaveStats{0u, 0u, 0ull, 0, 0};
+        st.last_record[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n_counters)
+        st.ep_counters[i] = 0ull;
+}
+
+// final score of each board's most recent finished episode (0 before the first one)
+__global__ void __launch_bounds__(kBlock) export_last_scores_kernel(const uint4 *last_record, uint32_t n, int32_t *out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n)
+        out[i] = static_cast<int32_t>(record_score(load_board(last_record, i)));
 }
 
 // ------------------------------------------------------------------------ synthetic policy
@@ -802,17 +638,18 @@ __global__ void __launch_bounds__(kBlock) canonicalize_kernel(uint4 *boards, uin
 }
 
 // ----------------------------------------------------------------------------------- stats
-// Reduce the episode accumulators, the highest tile on any board and the histogram of the boards'
-// highest tiles (what ppo_train.py:77-81 logs per finished episode, here for the live boards) to one
-// StatsOut.  Block-level tree in LDS first, then ONE set of atomics per block (a single hot word
+// Reduce to one StatsOut: the episode counters, the returns of the boards' most recent finished
+// episodes (score of last_record: count / sum / max), the highest tile on any board and the histogram
+// of the boards' highest tiles (what ppo_train.py:77-81 tallies per finished episode, here for the
+// live boards).  Block-level tree in LDS first, then ONE set of atomics per block (a single hot word
 // serialises at ~88 atomics/us on this chip, so per-wave atomics to one address would take hundreds of us).
 __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
                                                        StatsOut *out)
 {
-    __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock];
+    __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock], s_cnt[kBlock];
     __shared__ int s_max[kBlock], s_exp[kBlock];
     __shared__ unsigned int s_hist[32];
-    unsigned long long episodes = 0, illegal = 0, score_sum = 0;
+    unsigned long long episodes = 0, illegal = 0, score_sum = 0, count = 0;
     int max_score = 0, max_exp = 0;
     const uint32_t tid = threadIdx.x;
     if (tid < 32u)
@@ -820,24 +657,30 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
     __syncthreads();
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t wv = blockIdx.x * kBlock + tid; wv < n_waves; wv += stride) {
-        const WaveStats ws = st.wave_stats[wv];
-        episodes += ws.episodes;
-        illegal += ws.illegal_ends;
-        score_sum += ws.score_sum;
-        max_score = max(max_score, ws.max_score);
+        episodes += st.ep_counters[2u * wv];
+        illegal += st.ep_counters[2u * wv + 1u];
     }
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += stride) {
         const int h = static_cast<int>(highest(record_cells(load_board(st.boards, i))));
         max_exp = max(max_exp, h);
         atomicAdd(&s_hist[h & 31], 1u);
+        const Board last = load_board(st.last_record, i);
+        if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
+            const int sc = static_cast<int>(record_score(last));
+            count += 1;
+            score_sum += static_cast<unsigned long long>(sc);
+            max_score = max(max_score, sc);
+        }
     }
-    s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_max[tid] = max_score; s_exp[tid] = max_exp;
+    s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_cnt[tid] = count;
+    s_max[tid] = max_score; s_exp[tid] = max_exp;
     __syncthreads();
     for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
         if (tid < off) {
             s_ep[tid] += s_ep[tid + off];
             s_ill[tid] += s_ill[tid + off];
             s_sum[tid] += s_sum[tid + off];
+            s_cnt[tid] += s_cnt[tid + off];
             s_max[tid] = max(s_max[tid], s_max[tid + off]);
             s_exp[tid] = max(s_exp[tid], s_exp[tid + off]);
         }
@@ -846,8 +689,9 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
     if (tid == 0) {
         atomicAdd(&out->episodes, s_ep[0]);
         atomicAdd(&out->illegal_ends, s_ill[0]);
-        atomicAdd(&out->score_sum, s_sum[0]);
-        atomicMax(&out->max_score, s_max[0]);
+        atomicAdd(&out->last_count, s_cnt[0]);
+        atomicAdd(&out->last_score_sum, s_sum[0]);
+        atomicMax(&out->last_score_max, s_max[0]);
         atomicMax(&out->max_exp, static_cast<unsigned int>(s_exp[0]));
     }
     if (tid < 32u && s_hist[tid] != 0u)
@@ -869,12 +713,12 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
 {
     if (a.n == 0)
         return hipSuccess;
-    const dim3 g((a.n + kStepBlock - 1) / kStepBlock), b(kStepBlock);
+    const dim3 g = grid_for(a.n), b(kBlock);
     switch (action_dtype) {
-    case 0: hipLaunchKernelGGL((step_kernel<0, kStepBlock>), g, b, 0, s, a); break;
-    case 1: hipLaunchKernelGGL((step_kernel<1, kStepBlock>), g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((step_kernel<2, kStepBlock>), g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((step_kernel<3, kStepBlock>), g, b, 0, s, a); break;
+    case 0: hipLaunchKernelGGL(step_kernel<0>, g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL(step_kernel<1>, g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(step_kernel<2>, g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(step_kernel<3>, g, b, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1074,7 +918,15 @@ hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(clear_stats_kernel, grid_for(n), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u);
+    hipLaunchKernelGGL(clear_stats_kernel, grid_for(n), dim3(kBlock), 0, s, st, n, 2u * ((n + 63u) / 64u));
+    return hipGetLastError();
+}
+
+hipError_t launch_export_last_scores(const DeviceState &st, uint32_t n, int32_t *out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(export_last_scores_kernel, grid_for(n), dim3(kBlock), 0, s, st.last_record, n, out);
     return hipGetLastError();
 }
 

@@ -77,12 +77,14 @@ typedef struct {
     uint8_t *terminal_boards;/* [n][16] written only where terminated: the episode's last board */
 } g2048_step_io;
 
-/* Aggregate episode statistics (whole life of the engine since create/seed). */
+/* Episode statistics since create/seed. */
 typedef struct {
-    uint64_t episodes;       /* finished episodes */
+    uint64_t episodes;       /* finished episodes, all of them */
     uint64_t illegal_ends;   /* ... of which ended on an illegal move (game2048_env.py:91-95) */
-    int64_t score_sum;       /* sum of their final merge scores (game2048_env.py:86) */
-    int32_t max_score;       /* best final score */
+    uint64_t last_count;     /* boards that have finished at least one episode */
+    int64_t last_score_sum;  /* sum over those boards of the final merge score (game2048_env.py:86) of their MOST
+                              * RECENT finished episode (the engine keeps one terminal record per board) */
+    int32_t last_score_max;  /* best of those */
     uint32_t max_exp;        /* highest exponent currently on any board */
     uint32_t highest_hist[32]; /* highest_hist[k] = boards whose highest tile (game2048_env.py:190-192) is 2^k
                                 * right now (k = 0: empty board) -- what ppo_train.py:77-81 tallies */
@@ -179,15 +181,16 @@ int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream);
 int g2048_get_scores(const g2048_engine *e, int32_t *buf, void *stream);
 int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream);
 
-/* Final merge score of each board's most recently finished episode (written when a step
- * terminates; 0 before the first one): int32[n], host or device. */
+/* Final merge score of each board's most recently finished episode (0 before the first one):
+ * int32[n], host or device.  A step that ends an episode stores the 16-byte terminal record; this call
+ * turns the records into scores (potential - deficit) with a kernel. */
 int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream);
 
 /* Raw device pointers of the engine-owned state for zero-copy views: the board RECORDS
- * (uint8[n][16]; cell = byte & 0x1f, see "RECORD" above) and last_score (int32[n]).  Valid until
- * g2048_destroy. */
+ * (uint8[n][16]; cell = byte & 0x1f, see "RECORD" above) and the terminal records of the most recent
+ * finished episodes (same format, all-zero = none yet).  Valid until g2048_destroy. */
 void *g2048_records_ptr(const g2048_engine *e);
-void *g2048_last_score_ptr(const g2048_engine *e);
+void *g2048_last_records_ptr(const g2048_engine *e);
 
 /* Reduce the episode bookkeeping on the device and copy the result to *out (synchronises `stream`). */
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
@@ -237,8 +240,9 @@ int g2048_canonicalize(uint8_t *boards, uint8_t *next_boards, uint8_t *actions, 
  *
  * One process per GPU: rank 0 calls g2048_comm_unique_id and hands the 128 bytes to the other ranks by
  * any means (torch.distributed.broadcast, MPI, a file); every rank then calls g2048_comm_create
- * (ncclCommInitRank).  g2048_allgather_returns enqueues ONE ncclAllGather of the engine's last_score
- * (int32[n], n equal on all ranks) into out[world * n] (device memory) on `stream`. */
+ * (ncclCommInitRank).  g2048_allgather_returns enqueues, on `stream`, the kernel that turns the engine's
+ * terminal records into returns (int32[n], n equal on all ranks) and ONE ncclAllGather of them into
+ * out[world * n] (device memory). */
 int g2048_comm_unique_id(uint8_t id[G2048_COMM_ID_BYTES]);
 int g2048_comm_create(int world, int rank, const uint8_t id[G2048_COMM_ID_BYTES], int device, g2048_comm **out);
 int g2048_comm_destroy(g2048_comm *c);

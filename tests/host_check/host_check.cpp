@@ -115,10 +115,9 @@ void hostcheck_step_batch(g2048o_batch *s, uint64_t n, uint64_t seed, uint64_t t
     }
 }
 
-// ---- the RECORD layout and the per-step kernel's flow (step_kernel + its block fixer in
-// g2048_kernels.hip), one board at a time: state lives in `records` (16 B per board: cells + packed
-// score deficit); the plain boards / scores of the batch struct are exported after every call so
-// the test can compare them with the oracle's.
+// ---- the RECORD layout and the per-step kernel's flow (step_kernel in g2048_kernels.hip), one board
+// at a time: state lives in `records` (16 B per board: cells + packed score deficit); the plain boards /
+// scores of the batch struct are exported after every call so the test can compare them with the oracle's.
 static const uint32_t kLutHost[32] = {G2048_MOVE_LUT_WORDS};
 
 static MoveSel host_move_sel(uint32_t action)
@@ -182,55 +181,50 @@ void hostcheck_reset_records(g2048o_batch *s, uint8_t *records, uint64_t n, uint
     }
 }
 
-void hostcheck_step_records(g2048o_batch *s, uint8_t *records, uint64_t n, uint64_t seed, uint64_t t,
-                            uint64_t board_offset, float illegal_move_reward, int max_exp_i, int auto_reset)
+struct HostTables { // what LdsTables is on the device (g2048_kernels.hip)
+    MoveSel move_sel(uint32_t action) const { return host_move_sel(action); }
+    Board onehot_cell(uint32_t p) const
+    {
+        return Board{{onehot_cell_word(p, 0), onehot_cell_word(p, 1), onehot_cell_word(p, 2), onehot_cell_word(p, 3)}};
+    }
+};
+
+void hostcheck_fresh_record_lut(uint32_t w1, uint32_t w2, uint8_t out_lut[16], uint8_t out_ref[16])
 {
-    const uint32_t max_exp = (uint32_t)max_exp_i;
+    store_board(out_lut, fresh_record_lut(w1, w2, HostTables{}));
+    store_board(out_ref, fresh_record(w1, w2));
+}
+
+// step_kernel's body (g2048_kernels.hip): step_record + outputs + episode bookkeeping; last_records
+// [n][16] is the engine's last_record array.
+void hostcheck_step_records(g2048o_batch *s, uint8_t *records, uint8_t *last_records, uint64_t n, uint64_t seed, uint64_t t,
+                            uint64_t board_offset, float illegal_move_reward, int max_exp, int auto_reset)
+{
     for (uint64_t i = 0; i < n; ++i) {
-        // ---- owner lane (step_kernel)
-        const Board raw = load_board(records + 16 * i);
+        Board rec = load_board(records + 16 * i);
         const Words w = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(board_offset + i), 0u,
                                       (uint32_t)seed, (uint32_t)(seed >> 32));
         const uint32_t action = s->actions ? (s->actions[i] & 3u) : (w.w[3] >> 30);
-        Board cells = record_cells(raw);
-        uint32_t gain;
-        const bool legal = move_sel(cells, host_move_sel(action), gain);
-        const uint32_t n_empty = add_tile(cells, w.w[0], lanemask(legal));
-        bool end = false;
-        if (n_empty == 1u)
-            end = !has_equal_neighbours(cells);
-        if (max_exp != 0 && highest(cells) == max_exp)
-            end = true;
-        const bool terminated = legal ? end : true;
-        const uint32_t inc = (legal && (w.w[0] & 0xffffu) > 58982u) ? 0x80u : 0u;
-        Board out = raw;
-        record_update(out, cells, inc);
-        const bool do_reset = terminated && auto_reset != 0;
-        if (!do_reset)
-            store_board(records + 16 * i, out);
-        if (s->reward) s->reward[i] = legal ? (float)gain : illegal_move_reward;
-        if (s->terminated) s->terminated[i] = terminated;
-        if (s->illegal) s->illegal[i] = !legal;
-        if (s->highest) s->highest[i] = (uint8_t)highest(cells);
-        if (terminated) {
-            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, cells);
-            // ---- fixer lane (run_fixer): entry = {out, w1, w2, flags}
-            const uint32_t lm = lanemask(legal);
-            const uint32_t w1 = bfi(lm, w.w[1], w.w[0]), w2 = bfi(lm, w.w[2], w.w[1]);
-            s->last_score[i] = (int32_t)record_score(out);
+        const StepOut o = step_record(rec, action, w, (uint32_t)max_exp, auto_reset != 0, HostTables{});
+        store_board(records + 16 * i, rec);
+        if (s->reward) s->reward[i] = o.legal ? (float)o.gain : illegal_move_reward;
+        if (s->terminated) s->terminated[i] = o.terminated;
+        if (s->illegal) s->illegal[i] = !o.legal;
+        if (s->highest) s->highest[i] = (uint8_t)highest(record_cells(o.terminal));
+        if (o.terminated) {
+            store_board(last_records + 16 * i, o.terminal);
+            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, record_cells(o.terminal));
+            s->last_score[i] = (int32_t)record_score(load_board(last_records + 16 * i)); // g2048_get_last_scores
             s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
             s->ep_count[i] += 1;
-            if (do_reset) {
-                store_board(records + 16 * i, fresh_record(w1, w2));
-                s->ep_start[i] = (uint32_t)t;
-            }
+            if (auto_reset) s->ep_start[i] = (uint32_t)t;
         }
-        export_record(s, i, load_board(records + 16 * i));
+        export_record(s, i, rec);
     }
 }
 
 // the fused kernels' way through the record: unpack once, step_env, pack
-void hostcheck_step_records_unpacked(g2048o_batch *s, uint8_t *records, uint64_t n, uint64_t seed, uint64_t t,
+void hostcheck_step_records_unpacked(g2048o_batch *s, uint8_t *records, uint8_t *, uint64_t n, uint64_t seed, uint64_t t,
                                      uint64_t board_offset, float illegal_move_reward, int max_exp, int auto_reset)
 {
     for (uint64_t i = 0; i < n; ++i) {

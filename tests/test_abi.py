@@ -44,7 +44,7 @@ def test_abi_version(lib):
 def test_struct_layouts():
     from gym2048_amd import _lib
     assert C.sizeof(_lib.StepIO) == 56      # 7 x 8 bytes (int32 padded)
-    assert C.sizeof(_lib.Stats) == 160     # 32 + uint32 highest_hist[32]
+    assert C.sizeof(_lib.Stats) == 168     # 40 + uint32 highest_hist[32]
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -133,20 +133,21 @@ def test_reset_slots(host_check):
 # ------------------------------------------------------------------ board RECORD (cells + score deficit)
 
 class HostRecordBatch(OracleBatch):
-    """Mirror of step_kernel + its block fixer (g2048_kernels.hip) on the host: the state is the array
-    of 16-byte records; plain boards and scores are exported after every call."""
+    """Mirror of step_kernel (g2048_kernels.hip) on the host: the state is the array of 16-byte records
+    (+ the terminal records of finished episodes); plain boards and scores are exported after every call."""
 
     def __init__(self, hc, n, seed=0, board_offset=0, unpacked=False):
         super().__init__(n, seed, board_offset)
         self.hc = hc
         self.records = np.zeros((n, 16), np.uint8)
+        self.last_records = np.zeros((n, 16), np.uint8)
         self.step_fn = hc.hostcheck_step_records_unpacked if unpacked else hc.hostcheck_step_records
         u64, vp = C.c_uint64, C.c_void_p
         hc.hostcheck_reset_records.restype = None
         hc.hostcheck_reset_records.argtypes = [C.POINTER(_Batch), vp, u64, u64, u64, u64, C.c_uint32]
         for f in (hc.hostcheck_step_records, hc.hostcheck_step_records_unpacked):
             f.restype = None
-            f.argtypes = [C.POINTER(_Batch), vp, u64, u64, u64, u64, C.c_float, C.c_int, C.c_int]
+            f.argtypes = [C.POINTER(_Batch), vp, vp, u64, u64, u64, u64, C.c_float, C.c_int, C.c_int]
 
     def reset(self, first_slot=0, new_transaction=None):
         if new_transaction is None:
@@ -164,8 +165,8 @@ class HostRecordBatch(OracleBatch):
         self.t += 1
         self.fresh = False
         b = self._batch(actions)
-        self.step_fn(C.byref(b), self.records.ctypes.data, self.n, self.seed, self.t, self.board_offset,
-                     self.illegal_move_reward, self.max_exp, int(auto_reset))
+        self.step_fn(C.byref(b), self.records.ctypes.data, self.last_records.ctypes.data, self.n, self.seed, self.t,
+                     self.board_offset, self.illegal_move_reward, self.max_exp, int(auto_reset))
 
 
 def test_move_lut(host_check):
@@ -215,6 +216,16 @@ def test_potential_and_record_packing(host_check):
     assert host_check.hostcheck_record_deficit(rec.ctypes.data_as(U8P)) == (1 << 24) - 4
     host_check.hostcheck_record_bump(rec.ctypes.data_as(U8P), 1)
     assert host_check.hostcheck_record_deficit(rec.ctypes.data_as(U8P)) == 0 and np.array_equal(rec & 0x1F, cells)
+
+
+def test_fresh_record_through_the_one_tile_table(host_check):
+    rng = np.random.default_rng(4)
+    a, b = np.zeros(16, np.uint8), np.zeros(16, np.uint8)
+    words = rng.integers(0, 2 ** 32, size=(20000, 2), dtype=np.uint64)
+    words[:64, 0] = (np.arange(64) % 16) << 28 | 0xFFFF * (np.arange(64) // 32)   # every cell, both tile values
+    for w1, w2 in words:
+        host_check.hostcheck_fresh_record_lut(int(w1), int(w2), a.ctypes.data_as(U8P), b.ctypes.data_as(U8P))
+        assert np.array_equal(a, b), (hex(int(w1)), hex(int(w2)))
 
 
 @pytest.mark.parametrize("unpacked", [False, True])

@@ -154,7 +154,7 @@ def test_random_rollout_vs_oracle(torch_cuda, n, seed, offset, irw, max_tile, au
         b.max_exp = int(np.log2(max_tile)) if max_tile else 0
         b.reset()
     assert np.array_equal(g.boards, o.boards)
-    score_sum = illegal_ends = max_score = 0
+    illegal_ends = 0
     for s in range(64):
         g.step(None, auto_reset=auto_reset)
         o.step(None, auto_reset=auto_reset)
@@ -162,13 +162,17 @@ def test_random_rollout_vs_oracle(torch_cuda, n, seed, offset, irw, max_tile, au
             assert np.array_equal(getattr(g, f), getattr(o, f)), (f, s)
         done = o.terminated.astype(bool)
         assert np.array_equal(g.terminal_boards[done], o.terminal_boards[done])
-        score_sum += int(o.last_score[done].sum())
         illegal_ends += int((o.illegal.astype(bool) & done).sum())
-        max_score = max([max_score] + o.last_score[done].tolist())
     st = g.eng.episode_stats()
-    assert st["episodes"] == int(o.ep_count.sum()) and st["score_sum"] == score_sum
-    assert st["illegal_ends"] == illegal_ends and st["max_score"] == max_score
+    had = o.ep_count > 0                                    # boards that finished at least one episode
+    assert st["episodes"] == int(o.ep_count.sum()) and st["illegal_ends"] == illegal_ends
+    assert st["last_count"] == int(had.sum()) and st["last_score_sum"] == int(o.last_score[had].sum())
+    assert st["last_score_max"] == (int(o.last_score[had].max()) if had.any() else 0)
     assert st["max_exp"] == int(o.boards.max())
+    hist = np.bincount(o.boards.max(axis=1), minlength=32)
+    assert st["highest_hist"] == hist.tolist()
+    raw_last = g.eng.last_records().cpu().numpy()
+    assert np.array_equal((raw_last & 0x1F)[had], o.terminal_boards[had]) and not raw_last[~had].any()
 
 
 def test_action_dtypes_and_generated_actions(torch_cuda):
@@ -474,8 +478,22 @@ def test_full_size_conservation_over_a_rollout(torch_cuda):
     b.rollout(acts)
     st = a.episode_stats()
     assert st["episodes"] == int(term.sum(dtype=torch.int64))
-    assert int(rew.sum(dtype=torch.float64)) == st["score_sum"] + int(a.scores().sum(dtype=torch.int64))
-    assert 0 < st["illegal_ends"] <= st["episodes"] and st["max_score"] >= st["mean_score"] > 0
+    # every reward is a merge score; each one belongs either to a finished episode or to a running one.
+    # Sum of the finished ones, from the rollout buffers: episode return = sum of rewards up to its end.
+    run = torch.zeros(n, dtype=torch.float64, device=a.device)
+    finished = torch.zeros((), dtype=torch.float64, device=a.device)
+    last = torch.zeros(n, dtype=torch.float64, device=a.device)
+    for j in range(k):
+        run += rew[j]
+        done = term[j] != 0
+        finished += run[done].sum()
+        last = torch.where(done, run, last)
+        run[done] = 0
+    assert int(rew.sum(dtype=torch.float64)) == int(finished) + int(a.scores().sum(dtype=torch.int64))
+    assert torch.equal(a.last_scores().to(torch.float64), last)       # the returns the all-gather ships
+    assert st["last_score_sum"] == int(last.sum()) and st["last_score_max"] == int(last.max())
+    assert 0 < st["illegal_ends"] <= st["episodes"] and st["last_score_max"] >= st["mean_last_score"] > 0
+    assert sum(st["highest_hist"]) == n
     assert torch.equal(a.boards(), b.boards()) and torch.equal(a.scores(), b.scores())
     assert st == b.episode_stats() and a.clock == b.clock == k
     assert torch.equal(a.last_scores(), b.last_scores())

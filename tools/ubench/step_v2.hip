@@ -1,8 +1,8 @@
 // step_v2.hip -- A/B harness (measurement tool, not product): the round-1 step kernel (score array,
-// owner-lane reset, per-wave DPP bookkeeping; sources taken from git at build time into _v1/) against
-// the record-layout kernel with its block fixer, and the experiment switches of the latter, timed
-// interleaved in one process (HIP events, median over rounds).  Also cross-checks that both kernels play
-// the same games.   Usage: step_v2 [log2_boards] [rounds]
+// transposing move, per-wave DPP bookkeeping; sources taken from git at build time into _v1/, see
+// tools/ubench/build.sh) against the current record-layout kernel, timed interleaved in one process
+// (HIP events, median over rounds).  Also cross-checks that both kernels play the same games.
+// Usage: step_v2 [log2_boards] [rounds]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -19,12 +19,6 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
-
-template <int BLOCK, int X>
-static void launch_v2(const g2048::StepArgs &a)
-{
-    hipLaunchKernelGGL((g2048::step_kernel<1, BLOCK, X>), dim3((a.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, a);
-}
 
 int main(int argc, char **argv)
 {
@@ -45,10 +39,10 @@ int main(int argc, char **argv)
     // ---- v2 state
     g2048::StepArgs a2{};
     CHECK(hipMalloc(&a2.st.boards, (size_t)n * 16));
-    CHECK(hipMalloc(&a2.st.last_score, (size_t)n * 4));
-    CHECK(hipMalloc(&a2.st.wave_stats, (size_t)(n / 64 + 16) * sizeof(g2048::WaveStats)));
-    CHECK(hipMemset(a2.st.last_score, 0, (size_t)n * 4));
-    CHECK(hipMemset(a2.st.wave_stats, 0, (size_t)(n / 64 + 16) * sizeof(g2048::WaveStats)));
+    CHECK(hipMalloc(&a2.st.last_record, (size_t)n * 16));
+    CHECK(hipMalloc(&a2.st.ep_counters, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMemset(a2.st.last_record, 0, (size_t)n * 16));
+    CHECK(hipMemset(a2.st.ep_counters, 0, (size_t)(n / 64 + 16) * 16));
     uint8_t *actions, *term; float *reward;
     CHECK(hipMalloc(&actions, (size_t)n * launches));
     CHECK(hipMalloc(&term, (size_t)n * launches));
@@ -81,7 +75,8 @@ int main(int argc, char **argv)
         CHECK(hipMemcpy(s1.data(), a1.st.score, (size_t)n * 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(s2.data(), sc2, (size_t)n * 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(l1.data(), a1.st.last_score, (size_t)n * 4, hipMemcpyDeviceToHost));
-        CHECK(hipMemcpy(l2.data(), a2.st.last_score, (size_t)n * 4, hipMemcpyDeviceToHost));
+        CHECK(g2048::launch_export_last_scores(a2.st, n, sc2, 0));
+        CHECK(hipMemcpy(l2.data(), sc2, (size_t)n * 4, hipMemcpyDeviceToHost));
         printf("cross-check after 48 steps: boards %s, scores %s, last_score %s\n", h1 == h2 ? "equal" : "DIFFER",
                s1 == s2 ? "equal" : "DIFFER", l1 == l2 ? "equal" : "DIFFER");
         CHECK(hipFree(plain)); CHECK(hipFree(sc2));
@@ -91,16 +86,9 @@ int main(int argc, char **argv)
     auto io1 = [&](uint32_t j) { a1.t_lo = 100 + j; a1.actions = actions + (size_t)j * n; a1.reward = reward + (size_t)j * n; a1.terminated = term + (size_t)j * n; };
     auto io2 = [&](uint32_t j) { a2.t_lo = 100 + j; a2.actions = actions + (size_t)j * n; a2.reward = reward + (size_t)j * n; a2.terminated = term + (size_t)j * n; };
     vs.push_back({"v1  round-1 kernel (score array, owner reset, DPP stats), block 256", [&](uint32_t j) { io1(j); (void)g2048v1::launch_step(a1, 1, 0); }});
-    vs.push_back({"v2  records + LUT + fixer, block 512 (product)", [&](uint32_t j) { io2(j); launch_v2<512, 0>(a2); }});
-    vs.push_back({"v2  block 256", [&](uint32_t j) { io2(j); launch_v2<256, 0>(a2); }});
-    vs.push_back({"v2  block 1024", [&](uint32_t j) { io2(j); launch_v2<1024, 0>(a2); }});
-    vs.push_back({"v2  block 512, owner always stores (no holes), fixer overwrites", [&](uint32_t j) { io2(j); launch_v2<512, g2048::X_OWNERSTORE>(a2); }});
-    vs.push_back({"v2  block 256, owner always stores", [&](uint32_t j) { io2(j); launch_v2<256, g2048::X_OWNERSTORE>(a2); }});
-    vs.push_back({"v2  block 512, NO episode-end work at all (no hand-off, no fixer)", [&](uint32_t j) { io2(j); launch_v2<512, g2048::X_NOFIX>(a2); }});
-    vs.push_back({"v2  block 256, NO episode-end work", [&](uint32_t j) { io2(j); launch_v2<256, g2048::X_NOFIX>(a2); }});
-    vs.push_back({"v2  block 256, NO episode-end work, transposing move (no LUT), barrier kept", [&](uint32_t j) { io2(j); launch_v2<256, g2048::X_NOFIX | g2048::X_NOLUT>(a2); }});
-    vs.push_back({"v2  block 256, NO episode-end work, transposing move, NO barrier", [&](uint32_t j) { io2(j); launch_v2<256, g2048::X_NOFIX | g2048::X_NOLUT | g2048::X_NOBARRIER>(a2); }});
-    vs.push_back({"v2  block 512, fixer kept, transposing move (no LUT)", [&](uint32_t j) { io2(j); launch_v2<512, g2048::X_NOLUT>(a2); }});
+    vs.push_back({"v3  product step_kernel<1> (records, per-wave LDS tables, in-lane reset)", [&](uint32_t j) { io2(j); (void)g2048::launch_step(a2, 1, 0); }});
+    vs.push_back({"v3  product step_kernel<0> (synthetic actions)", [&](uint32_t j) { io2(j); (void)g2048::launch_step(a2, 0, 0); }});
+    vs.push_back({"v3  step_kernel<1>, no outputs", [&](uint32_t j) { io2(j); a2.reward = nullptr; a2.terminated = nullptr; (void)g2048::launch_step(a2, 1, 0); }});
 
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
