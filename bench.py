@@ -14,13 +14,18 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): rank r owns global 
 the end of the rollout, inside the timed region.  scaling = "weak".
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- algorithmic bytes (38 B/env-step) / HIP-event time per launch vs the 8 TB/s HBM peak
+  roofline     -- algorithmic bytes (38 B/env-step) / HIP-event time per launch vs the 8 TB/s HBM peak;
+                  `traffic` = HBM bytes per launch from the committed PMC profile, printed only while the
+                  profile was taken from the kernel sources that are being run (hash of csrc/), else null
   cpu_baseline -- the C oracle (oracle/, "port") timed on this box's host cores on a bounded sample
-  extras       -- fused K-step rollout kernel, a 2^24-board run that really streams HBM, Python port
+  extras       -- a 2^24-board run that really streams HBM (best of 3), the step + one-hot observation
+                  figure, the policy-in-the-loop figure (BASELINE configs[4]), fused rollout kernels,
+                  numpy-RNG mode, Python port
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -104,14 +109,41 @@ def python_port_rate() -> float:
     return n / (time.perf_counter() - t0)
 
 
+CSRC_FILES = ("gym-2048_amd/csrc/g2048_device.h", "gym-2048_amd/csrc/g2048_kernels.hip",
+              "gym-2048_amd/csrc/g2048_kernels.h", "gym-2048_amd/csrc/g2048_api.hip", "gym-2048_amd/csrc/g2048_pcg64.h",
+              "include/g2048.h")
+
+
+def csrc_hash() -> str:
+    """sha256[:16] over the kernel / ABI sources: stamps a PMC profile with the code it was taken from."""
+    h = hashlib.sha256()
+    for rel in CSRC_FILES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic():
-    """HBM bytes per launch from the committed PMC profile (profiles/traffic_latest.json), or None."""
+    """The committed PMC profile (profiles/traffic_latest.json: HBM bytes per launch of step_kernel at
+    2^20 boards, the tag of the profile and the hash of the sources it was taken from), or None."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             return json.load(f)
     except (OSError, ValueError):
         return None
+
+
+def traffic_for_current_sources(boards: int):
+    """(bytes_per_launch | None, provenance): the number is reported only for the profiled batch size and
+    only while the kernel sources still hash to what was profiled -- a stale profile prints null."""
+    t = load_traffic()
+    if not t:
+        return None, {"profile": None}
+    prov = {"profile": t.get("profile"), "profiled_csrc": t.get("csrc_sha16"), "current_csrc": csrc_hash()}
+    if boards != (1 << 20) or t.get("csrc_sha16") != prov["current_csrc"]:
+        return None, prov
+    return t.get("bytes_per_launch"), prov
 
 
 def main():
@@ -166,18 +198,22 @@ def main():
             return allgather_returns(local.cpu(), shard)
         return allgather_returns(local, shard)
 
-    # ---- warm-up: W untimed steps (own small buffers), then inputs for the timed K steps
-    if W > 0:
-        wa = eng.random_actions(W)
-        eng.rollout(wa)
-        del wa
-    actions = eng.random_actions(K)                      # [K][B] u8, resident in HBM
-    reward = torch.empty((K, B), dtype=torch.float32, device=dev)
-    terminated = torch.empty((K, B), dtype=torch.uint8, device=dev)
-    reward.zero_()
-    terminated.zero_()
+    # ---- inputs and outputs of the timed K steps: allocated, generated and TOUCHED before any timing
+    #      (a fresh box's first touch of a page must not land in the timed region), then the W untimed
+    #      warm-up steps, then -- with nothing in between -- the timed region
+    actions = eng.random_actions(K, t_first=eng.clock + 1 + W)   # [K][B] u8, resident in HBM
+    reward = torch.zeros((K, B), dtype=torch.float32, device=dev)
+    terminated = torch.zeros((K, B), dtype=torch.uint8, device=dev)
     if world > 1:                                        # warm the collective once (communicator setup)
         gather_returns()
+    if W > 0:
+        wa = eng.random_actions(W)
+        wr = torch.zeros((min(W, 8), B), dtype=torch.float32, device=dev)
+        wt = torch.zeros((min(W, 8), B), dtype=torch.uint8, device=dev)
+        for j0 in range(0, W, 8):                        # same kernel, same outputs as the timed steps
+            kk = min(8, W - j0)
+            eng.rollout(wa[j0:j0 + kk], reward=wr[:kk], terminated=wt[:kk])
+        del wa, wr, wt
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
@@ -185,7 +221,8 @@ def main():
     ev0.record()
     eng.rollout(actions, reward=reward, terminated=terminated)   # EXACTLY K step launches
     ev1.record()
-    gathered = gather_returns()                                  # once per rollout (N > 1: RCCL)
+    # the path's only exchange: once per rollout, N > 1 only (RCCL all-gather of the episodic returns)
+    gathered = gather_returns() if world > 1 else None
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_region_ms = ev0.elapsed_time(ev1)
@@ -195,7 +232,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_region_ms = float(tmax[0]), float(tmax[1])
-    assert gathered.numel() == B * world
+    assert gathered is None or gathered.numel() == B * world
 
     # sanity inside the bench: the rollout really happened (episodes finished, rewards written)
     stats = eng.episode_stats()
@@ -203,7 +240,8 @@ def main():
     value = total_steps / elapsed
     launch_us = kernel_region_ms * 1e3 / K
     achieved = ALGO_BYTES_PER_STEP * B / (launch_us * 1e-6) / 1e9
-    traffic = load_traffic()
+    traffic, traffic_prov = traffic_for_current_sources(B)
+    working_set_mib = (B * 16 * 2 + B * 6) / 2**20
 
     out = {
         "metric": ("env-steps/sec at batch=2^20 per MI355X" if B == (1 << 20) else f"env-steps/sec at batch={B} per MI355X"), "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -217,9 +255,12 @@ def main():
                    else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic.get("bytes_per_launch") if (traffic and B == (1 << 20)) else None,
+                     "traffic": traffic, "traffic_provenance": traffic_prov,
                      "kernel": "g2048::step_kernel<1>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
-                     "launch_us": launch_us},
+                     "launch_us": launch_us,
+                     "note": (f"the {working_set_mib:.0f} MiB of board records touched per launch sit in the 256 MiB "
+                              "Infinity Cache at this batch size, so this is a cache-resident figure; "
+                              "extras.streaming_2p24 is the run that streams HBM") if B <= (1 << 22) else None},
         "episodes_finished": int(stats["episodes"]), "mean_last_episode_score": stats["mean_last_score"],
     }
 
@@ -242,30 +283,63 @@ def main():
             extras["fused_rollout_with_io_steps_per_s"] = kf2 * B / (time.perf_counter() - t1)
         except Exception as exc:  # pragma: no cover
             extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
-        # (b) a batch that does not fit L2 + Infinity Cache: 2^24 boards (256 MiB of boards)
+        # (a3) the env-step INCLUDING the observation the reference's step() returns (stack(), game2048_env.py:100):
+        #      step_kernel + onehot_kernel (uint8 [B,16,4,4], +256 B per env-step), best of 3 x 20 steps
+        try:
+            obs = torch.zeros((B, 16, 4, 4), dtype=torch.uint8, device=dev)
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for j in range(20):
+                    eng.rollout(actions[j:j + 1], reward=reward[j:j + 1], terminated=terminated[j:j + 1])
+                    eng.observe_onehot(out=obs)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 20
+                best = us if best is None else min(best, us)
+            extras["step_plus_onehot_u8"] = {"us_per_step": best, "steps_per_s": B / (best * 1e-6),
+                                             "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP + 16 + 256,
+                                             "achieved_GBs": (ALGO_BYTES_PER_STEP + 16 + 256) * B / (best * 1e-6) / 1e9}
+            del obs
+        except Exception as exc:  # pragma: no cover
+            extras["step_plus_onehot_u8"] = {"error": str(exc)}
+        # (b) a batch that does not fit L2 + Infinity Cache: 2^24 boards (256 MiB of records).  Every buffer
+        #     is written once before timing (first touch), 8 warm-up launches, best of 3 timed rollouts.
         del reward, terminated, actions
         try:
-            nb, kb = 1 << 24, 40
+            nb, kb = 1 << 24, 24
             big = Batched2048(nb, device=local_rank, seed=SEED)
             big.reset()
             ab = big.random_actions(kb)
-            rb = torch.empty((kb, nb), dtype=torch.float32, device=dev)
-            tb = torch.empty((kb, nb), dtype=torch.uint8, device=dev)
+            rb = torch.zeros((kb, nb), dtype=torch.float32, device=dev)
+            tb = torch.zeros((kb, nb), dtype=torch.uint8, device=dev)
             big.rollout(ab[:8], reward=rb[:8], terminated=tb[:8])
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            big.rollout(ab, reward=rb, terminated=tb)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / kb
-            extras["streaming_2p24"] = {"boards": nb, "steps": kb, "launch_us": us,
+            runs = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                big.rollout(ab, reward=rb, terminated=tb)
+                e1.record()
+                torch.cuda.synchronize()
+                runs.append(e0.elapsed_time(e1) * 1e3 / kb)
+            us = min(runs)
+            extras["streaming_2p24"] = {"boards": nb, "steps": kb, "launch_us": us, "launch_us_runs": runs,
                                         "steps_per_s": nb / (us * 1e-6),
-                                        "achieved_GBs": ALGO_BYTES_PER_STEP * nb / (us * 1e-6) / 1e9}
+                                        "achieved_GBs": ALGO_BYTES_PER_STEP * nb / (us * 1e-6) / 1e9,
+                                        "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
             big.close()
             del ab, rb, tb
         except Exception as exc:  # pragma: no cover - memory pressure on a shared box
             extras["streaming_2p24"] = {"error": str(exc)}
+        # (b1) BASELINE configs[4]: the env driven by a ppo_train.py-shaped policy on the same GPU (bench_policy.py)
+        try:
+            import bench_policy
+            extras["policy_loop"] = bench_policy.run(boards=B, steps=3, warmup=1)
+        except Exception as exc:  # pragma: no cover
+            extras["policy_loop"] = {"error": str(exc)}
         # (b2) numpy-compatible RNG mode (the reference's own PCG64 per board, seeded on the device)
         try:
             nn, kn = 1 << 20, 20

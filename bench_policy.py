@@ -48,15 +48,9 @@ def build_policy(torch, filters=64, blocks=4):
         *[Residual(filters) for _ in range(blocks)], nn.Flatten(), nn.Linear(filters * 16, 4))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--boards", type=int, default=1 << 20)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chunk", type=int, default=1 << 17, help="policy forward batch")
-    ap.add_argument("--dtype", default="float16", choices=["float16", "float32"])
-    args = ap.parse_args()
-
+def run(boards=1 << 20, steps=20, warmup=3, chunk=1 << 17, dtype="float16") -> dict:
+    """The measurement; returns the JSON-able result (bench.py embeds it as extras.policy_loop)."""
+    args = argparse.Namespace(boards=boards, steps=steps, warmup=warmup, chunk=chunk, dtype=dtype)
     import torch
     if not torch.cuda.is_available():
         sys.exit("needs a ROCm GPU")
@@ -64,12 +58,12 @@ def main():
     ge.build_hip()
     from gym2048_amd.batched import Batched2048
 
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     dt = getattr(torch, args.dtype)
     torch.manual_seed(0)
     policy = build_policy(torch).to(dev).to(dt).eval().to(memory_format=torch.channels_last)
     n = args.boards
-    eng = Batched2048(n, seed=42)
+    eng = Batched2048(n, device=dev.index, seed=42)
     eng.reset()
     obs = torch.empty((n, 16, 4, 4), dtype=dt, device=dev)
     actions = torch.empty(n, dtype=torch.int64, device=dev)
@@ -103,15 +97,27 @@ def main():
     policy_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
     step_ms = sum(t[2].elapsed_time(t[3]) for t in timers) / args.steps
     stats = eng.episode_stats()
-    print(json.dumps({
+    eng.close()
+    return ({
         "metric": "env-steps/sec with a ppo_train.py-shaped policy in the loop (BASELINE configs[4])",
         "value": n * args.steps / wall, "unit": "env-steps/s", "boards": n, "steps": args.steps,
         "policy_dtype": args.dtype, "policy_chunk": args.chunk,
         "ms_per_step": {"onehot": onehot_ms, "policy_forward_argmax": policy_ms, "env_step": step_ms,
                         "wall": wall * 1e3 / args.steps},
         "env_fraction_of_loop": (onehot_ms + step_ms) / (onehot_ms + policy_ms + step_ms),
-        "host_copies": 0, "episodes_finished": int(stats["episodes"]), "mean_episode_score": stats["mean_score"],
-        "max_tile": 1 << int(stats["max_exp"])}))
+        "host_copies": 0, "episodes_finished": int(stats["episodes"]),
+        "mean_last_episode_score": stats["mean_last_score"], "max_tile": 1 << int(stats["max_exp"])})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, default=1 << 20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chunk", type=int, default=1 << 17, help="policy forward batch")
+    ap.add_argument("--dtype", default="float16", choices=["float16", "float32"])
+    a = ap.parse_args()
+    print(json.dumps(run(a.boards, a.steps, a.warmup, a.chunk, a.dtype)))
 
 
 if __name__ == "__main__":

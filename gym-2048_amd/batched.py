@@ -199,10 +199,11 @@ class Batched2048:
         return self.reward, self.terminated
 
     def rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None, auto_reset: bool = True,
-                fused: bool = False):
+                fused: bool = False, terminal_boards=None):
         """``k`` steps without returning to Python: ``actions`` is ``[k, n]`` (or ``k`` as an int for
-        the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers.  ``fused=True``
-        runs them as ONE launch with the boards in registers (same outputs, ``g2048_rollout_fused``)."""
+        the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers (``terminal_boards``:
+        ``[k, n, 16]``, rows written only where an episode ended; not with ``fused``).  ``fused=True`` runs
+        them as ONE launch with the boards in registers (same outputs, ``g2048_rollout_fused``)."""
         if isinstance(actions, int):
             k, act = actions, None
         else:
@@ -218,7 +219,11 @@ class Batched2048:
             if t.dtype != dt and not (dt == torch.uint8 and t.dtype == torch.bool):
                 raise TypeError(f"rollout buffer has dtype {t.dtype}; the kernels write {dt} "
                                 "(reward float32; terminated / illegal / highest uint8 or bool)")
-        io = self._io(act, reward, terminated, illegal, highest, None)
+        if terminal_boards is not None and (tuple(terminal_boards.shape) != (k, self.n_envs, 16)
+                                            or terminal_boards.dtype != torch.uint8
+                                            or not terminal_boards.is_contiguous() or terminal_boards.device != self.device):
+            raise ValueError("terminal_boards must be a contiguous uint8 [k, n_envs, 16] tensor on the engine's device")
+        io = self._io(act, reward, terminated, illegal, highest, terminal_boards)
         fn = self._lib.g2048_rollout_fused if fused else self._lib.g2048_rollout
         check(fn(self._h, k, C.byref(io), self.n_envs, int(auto_reset), self._stream()))
         self._fresh = False
@@ -418,6 +423,11 @@ class Batched2048:
 
     def highest_numpy(self) -> np.ndarray:
         return self.query()[1].cpu().numpy()
+
+    def set_clock(self, t: int):
+        """Set the transaction counter (the next step is transaction ``t + 1``)."""
+        check(self._lib.g2048_set_clock(self._h, int(t)))
+        self._fresh = False
 
     def add_tile(self, slot: int):
         """game2048_env.py:166-176 from spawn slot ``slot`` of the current transaction."""

@@ -18,6 +18,16 @@ import numpy as np
 from .render import GRID_SIZE, render_board
 
 
+def _env_base():
+    """``gymnasium.Env`` when gymnasium is installed -- ``gym.make('2048-v0')`` and wrappers such as
+    ``RecordVideo`` (ppo_train.py:102) insist on real ``gym.Env`` instances -- else ``object``."""
+    try:
+        import gymnasium
+        return gymnasium.Env
+    except ImportError:
+        return object
+
+
 class IllegalMove(Exception):
     """game2048_env.py:14-15."""
 
@@ -62,7 +72,7 @@ def _values_to_exp(v):
     return out
 
 
-class Game2048Env:
+class Game2048Env(_env_base()):
     metadata = {"render_modes": ["ansi", "human", "rgb_array"], "render_fps": 4}  # game2048_env.py:35
     _all_positions = [(r, c) for r in range(4) for c in range(4)]                  # game2048_env.py:36
 
@@ -116,6 +126,8 @@ class Game2048Env:
 
     def reset(self, seed=None, options=None):
         """game2048_env.py:102-111."""
+        if _env_base() is not object:
+            super().reset(seed=seed)          # :103 (gymnasium bookkeeping: np_random, which this env does not draw from)
         if seed is not None:
             self._eng.seed(int(seed))
             self._slot = 0

@@ -142,3 +142,39 @@ class Transitions:
         return Transitions(exp_to_values(bo.cpu().numpy()).reshape(-1, 4, 4), ao.cpu().numpy(),
                            np.tile(self.reward.reshape(-1), 8), exp_to_values(no.cpu().numpy()).reshape(-1, 4, 4),
                            np.tile(self.done.reshape(-1), 8))
+
+    # ------------------------------------------------------------------ canonicalisation on the device
+    def canonicalize(self, device=0):
+        """Symmetric-board canonicalisation (the inverse view of ``augment``): every row is
+        replaced by the lexicographically smallest (row-major board) of its eight symmetries -- the ones
+        training_data.py:257-299 generates -- with the action remapped and ``next_x`` turned the same way.
+        One launch of ``canonicalize_kernel`` (g2048_canonicalize).  Returns ``(Transitions, symmetry)`` where
+        ``symmetry[i] = 2 * clockwise_quarter_turns + hflip`` is the variant that was applied."""
+        b, nb, a, sym = canonicalize_device(values_to_exp(self.x).reshape(-1, 16), self.action.reshape(-1),
+                                            values_to_exp(self.next_x).reshape(-1, 16), device)  # noqa: E501
+        return (Transitions(exp_to_values(b).reshape(-1, 4, 4), a, self.reward.reshape(-1),
+                            exp_to_values(nb).reshape(-1, 4, 4), self.done.reshape(-1)), sym)
+
+
+def canonicalize_device(boards_exp, actions=None, next_boards_exp=None, device=0):
+    """uint8 exponent boards ``[n, 16]`` (+ optional actions ``[n]`` and next boards) -> canonical form, on
+    ``cuda:device`` through ``g2048_canonicalize``.  Returns host arrays ``(boards, next_boards | None,
+    actions | None, symmetry)``."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", device)
+    b = torch.as_tensor(np.ascontiguousarray(boards_exp, dtype=np.uint8).reshape(-1, 16)).to(dev)
+    n = b.shape[0]
+    nb = None if next_boards_exp is None else torch.as_tensor(
+        np.ascontiguousarray(next_boards_exp, dtype=np.uint8).reshape(n, 16)).to(dev)
+    a = None if actions is None else torch.as_tensor(np.ascontiguousarray(actions).reshape(n).astype(np.uint8)).to(dev)
+    sym = torch.empty(n, dtype=torch.uint8, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.g2048_canonicalize(b.data_ptr(), None if nb is None else nb.data_ptr(),
+                                      None if a is None else a.data_ptr(), n, sym.data_ptr(), stream))
+    return (b.cpu().numpy(), None if nb is None else nb.cpu().numpy(), None if a is None else a.cpu().numpy(),
+            sym.cpu().numpy())

@@ -10,8 +10,9 @@ stepped by one HIP launch.  It mirrors what that stack hands to the learner:
   ``illegal_move`` (what ppo_train.py:77-79 reads) and ``TimeLimit.truncated = False``;
 * envs that did not finish share one read-only empty info dict (SB3 only reads infos).
 
-SB3 / gymnasium are imported lazily and only for the space objects; the adapter is duck-typed and
-works without them.
+When stable_baselines3 is importable the class derives from its ``VecEnv`` (and ``Game2048Env`` from
+``gymnasium.Env``), so ``PPO(env=Vec2048(...))`` / ``gym.make('2048-v0')`` accept them unchanged; without
+those packages (this image) the same classes are plain objects with the same surface.
 """
 from __future__ import annotations
 
@@ -24,7 +25,17 @@ from .env import make_spaces
 _EMPTY_INFO: dict = {}
 
 
-class Vec2048:
+def _vec_env_base():
+    """SB3's ``VecEnv`` when stable_baselines3 is installed -- ``PPO(env=...)`` wraps anything that is not
+    a ``VecEnv`` instance into a ``DummyVecEnv`` (ppo_train.py:123) -- else ``object``."""
+    try:
+        from stable_baselines3.common.vec_env import VecEnv
+        return VecEnv
+    except ImportError:
+        return object
+
+
+class Vec2048(_vec_env_base()):
     metadata = {"render_modes": ["ansi", "human", "rgb_array"], "render_fps": 4}
 
     def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
@@ -34,8 +45,10 @@ class Vec2048:
             from .batched import Batched2048
             engine = Batched2048(n_envs, device=device, seed=seed, board_offset=board_offset, rng=rng)
         self.engine = engine
-        self.num_envs = int(n_envs)
         self.action_space, self.observation_space = make_spaces()
+        if _vec_env_base() is not object:
+            super().__init__(int(n_envs), self.observation_space, self.action_space)
+        self.num_envs = int(n_envs)
         self.obs_dtype = np.dtype(obs_dtype)
         self.render_mode = None
         self._illegal_move_reward = float(illegal_move_reward)

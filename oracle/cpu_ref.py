@@ -253,3 +253,29 @@ def values_to_exp(values) -> np.ndarray:
 def exp_to_values(exps) -> np.ndarray:
     e = np.asarray(exps).astype(np.int64)
     return np.where(e > 0, np.int64(1) << e, 0)
+
+
+# ------------------------------------------------------------------ symmetries (training_data.py:257-299)
+def symmetry_variant(board4x4, action, variant):
+    """Variant ``2 * k + flip`` of training_data.augment(): hflip first (np.flip along the columns, actions
+    1 <-> 3; training_data.py:257-273), then k clockwise quarter turns (np.rot90 with axes=(1, 0) on one
+    board = axes=(2, 1) on the batch, action + k mod 4; :275-280)."""
+    import numpy as np
+    b = np.asarray(board4x4).reshape(4, 4)
+    flip, k = variant & 1, variant >> 1
+    if flip:
+        b = np.flip(b, 1)
+        action = {1: 3, 3: 1}.get(int(action), int(action))
+    if k:
+        b = np.rot90(b, k=k, axes=(1, 0))
+        action = (int(action) + k) % 4
+    return b, int(action)
+
+
+def canonicalize(board4x4, action=0, next_board4x4=None):
+    """Lexicographically smallest (row-major) of the eight symmetries, lowest variant index on ties.
+    Returns (board, action, next_board | None, variant)."""
+    best = min(range(8), key=lambda v: (tuple(symmetry_variant(board4x4, action, v)[0].reshape(16)), v))
+    b, a = symmetry_variant(board4x4, action, best)
+    nb = None if next_board4x4 is None else symmetry_variant(next_board4x4, 0, best)[0]
+    return b, a, nb, best

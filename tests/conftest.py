@@ -51,6 +51,19 @@ def host_check():
     return lib
 
 
+@pytest.fixture(scope="session")
+def torch_cuda():
+    """torch with a ROCm device and every native piece built.  On a box without a GPU the `gpu` tests
+    are skipped (a plain `pytest` run stays green); on the GPU box they run and the product raises
+    G2048Error if its HIP library is missing -- there is no fallback to skip into."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU (torch.cuda.is_available() is False)")
+    import __graft_entry__ as ge
+    ge.build()
+    return torch
+
+
 TRAJECTORIES = ["traj_random_seed42", "traj_random_offset", "traj_greedy_irw", "traj_greedy_max256",
                 "traj_noautoreset"]
 

@@ -320,6 +320,77 @@ def gen_training_data_fixtures(report):
     return base
 
 
+def gen_render_fixture(ref, rng):
+    """render('ansi') text of the reference (game2048_env.py:113-115,156-163) for 24 states: right after
+    reset (score is the int 0), during play (score is a float), and set boards with wide tiles."""
+    boards, scores, score_is_int, texts = [], [], [], []
+
+    def grab(env):
+        boards.append(values_to_exp(env.get_board()).reshape(16))
+        scores.append(float(env.score))
+        score_is_int.append(isinstance(env.score, int))
+        texts.append(env.render(mode="ansi").getvalue())
+
+    d = RefDriver(ref, 123, board=5)
+    grab(d.env)                                   # fresh env: "Score: 0"
+    for t in range(40):
+        legal = d.legal_actions()
+        d.step(legal[t % len(legal)] if legal else 0)
+        if t % 3 == 0:
+            grab(d.env)
+    for _ in range(8):                            # arbitrary boards up to 65536, arbitrary float scores
+        env = ref.Game2048Env()
+        e = rng.integers(0, 17, 16)
+        e[rng.random(16) < 0.35] = 0
+        env.set_board(np.where(e > 0, 1 << e, 0).reshape(4, 4))
+        env.score = float(rng.integers(0, 200000)) * 4.0
+        grab(env)
+    env = ref.Game2048Env(render_mode="ansi")      # mode taken from render_mode (:114-115), empty board
+    env.set_board(np.zeros((4, 4), dtype=int))
+    boards.append(np.zeros(16, np.uint8)); scores.append(0.0); score_is_int.append(True)
+    texts.append(env.render().getvalue())
+    return dict(boards=np.array(boards, np.uint8), scores=np.array(scores), score_is_int=np.array(score_is_int),
+                texts=np.array(texts))
+
+
+def gen_canonical_table(rng, n=1024):
+    """Symmetric-board canonicalisation pinned to the reference's own symmetry code: the eight
+    variants of every transition are produced by training_data.hflip()/rotate() (training_data.py:257-280,
+    in augment()'s order), and the canonical one is the lexicographically smallest board (row-major), lowest
+    variant index on ties.  Includes boards with symmetric duplicates (ties)."""
+    import training_data as td_mod
+    x = random_boards(rng, n, max_exp=12)
+    x[: n // 8] = 0                                     # sparse boards: many ties between symmetries
+    x[: n // 8, 0] = rng.integers(1, 5, n // 8)
+    x[n // 8: n // 4] = np.repeat(rng.integers(1, 6, (n // 8, 1)), 16, axis=1)   # constant boards: all 8 tie
+    nx = random_boards(rng, n, max_exp=12)
+    a = rng.integers(0, 4, n)
+    vals = lambda e: np.where(e > 0, 1 << e.astype(np.int64), 0)  # noqa: E731
+    variants = []
+    for flip in (False, True):
+        for k in range(4):
+            td = td_mod.training_data()
+            for i in range(n):
+                td.add(vals(x[i]).reshape(4, 4), int(a[i]), 0.0, vals(nx[i]).reshape(4, 4), False)
+            if flip:
+                td.hflip()
+            if k:
+                td.rotate(k)
+            variants.append((2 * k + int(flip), td.get_x().reshape(n, 16).copy(), td.get_y_digit().reshape(n).copy(),
+                             td.get_next_x().reshape(n, 16).copy()))
+    variants.sort(key=lambda v: v[0])
+    canon_x, canon_a, canon_nx, sym = [], [], [], []
+    for i in range(n):
+        best = min(range(8), key=lambda v: (tuple(variants[v][1][i]), v))
+        sym.append(best)
+        canon_x.append(values_to_exp(variants[best][1][i]))
+        canon_a.append(variants[best][2][i])
+        canon_nx.append(values_to_exp(variants[best][3][i]))
+    return dict(boards=x.astype(np.uint8), actions=a.astype(np.uint8), next_boards=nx.astype(np.uint8),
+                canon_boards=np.array(canon_x, np.uint8).reshape(n, 16), canon_actions=np.array(canon_a, np.uint8),
+                canon_next=np.array(canon_nx, np.uint8).reshape(n, 16), symmetry=np.array(sym, np.uint8))
+
+
 def gen_reference_test_kats(ref):
     """Re-capture, by calling the reference, the values its own unit tests pin
     (test_game2048_env.py:13-34 shift rows, :40-98 move board, :113-151 isend, :165-217 step)."""
@@ -485,6 +556,7 @@ def main():
     ap.add_argument("--validate-steps", type=int, default=1_000_000)
     ap.add_argument("--only-numpy", action="store_true", help="only (re)generate the numpy-RNG trajectories")
     ap.add_argument("--only-data", action="store_true", help="only (re)generate the training_data fixtures")
+    ap.add_argument("--only-round2", action="store_true", help="only (re)generate render_ansi / canonical_table")
     args = ap.parse_args()
     ref = import_reference()
     rng = np.random.default_rng(20480)
@@ -498,6 +570,11 @@ def main():
 
     if args.only_data:
         save("training_data_fixture.npz", gen_training_data_fixtures(report))
+        print("\n".join(report))
+        return
+    if args.only_round2:
+        save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
+        save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
         print("\n".join(report))
         return
     save("training_data_fixture.npz", gen_training_data_fixtures(report))
@@ -520,6 +597,8 @@ def main():
     save("traj_greedy_max256.npz", gen_trajectories(ref, "greedy_max256", 2024, 16, 768, "greedy",
                                                     max_tile=256))
     save("traj_noautoreset.npz", gen_trajectories(ref, "noautoreset", 5, 16, 96, "random", auto_reset=False))
+    save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
+    save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
     validate(ref, args.validate_steps, report)
     time_reference(ref, report)
     with open(os.path.join(HERE, "VALIDATION.txt"), "w") as f:

@@ -1,0 +1,200 @@
+"""GPU: the parts of the C ABI that nothing else drives -- add_tile in both RNG modes, set_scores / set_clock,
+terminal_boards through g2048_rollout, the action generator's step-axis slabs, canonicalisation, the RCCL
+collective in its degenerate one-rank form."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+I64x16 = C.c_int64 * 16
+
+
+def _values(e):
+    return I64x16(*[0 if x == 0 else 1 << int(x) for x in e])
+
+
+def _exps(M):
+    return [0 if v == 0 else int(v).bit_length() - 1 for v in M]
+
+
+def _random_boards(rng, n):
+    b = rng.integers(1, 12, (n, 16)).astype(np.uint8)
+    b[rng.random((n, 16)) < rng.random((n, 1))] = 0      # every fill level, including full and empty boards
+    return b
+
+
+def test_add_tile_spawn_stream_vs_oracle(torch_cuda):
+    """g2048_add_tile (game2048_env.py:166-176) for several slots of a transaction, incl. slots >= 4 (second
+    Philox block) and full boards (the reference asserts there; the engine leaves them alone)."""
+    from gym2048_amd.batched import Batched2048
+    import oracle
+    lib = oracle.load()
+    rng = np.random.default_rng(2)
+    n, seed, off = 4096, 99, 1 << 21
+    boards = _random_boards(rng, n)
+    eng = Batched2048(n, seed=seed, board_offset=off)
+    eng.set_boards(boards)
+    eng.set_scores(np.arange(n, dtype=np.int32) * 4)
+    eng.set_clock(17)
+    want = boards.copy()
+    for slot in (0, 1, 2, 5):
+        eng.add_tile(slot)
+        for i in range(n):
+            M = _values(want[i])
+            if lib.g2048o_add_tile(M, lib.g2048o_spawn_word(seed, 17, off + i, slot)) >= 0:
+                want[i] = _exps(M)
+        assert np.array_equal(eng.get_boards().reshape(n, 16), want), slot
+    assert np.array_equal(eng.get_scores(), np.arange(n, dtype=np.int32) * 4)     # add_tile never scores
+    assert eng.clock == 17
+
+
+def test_add_tile_numpy_mode_vs_oracle(torch_cuda):
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch, load
+    lib = load()
+    rng = np.random.default_rng(3)
+    n, seed = 2048, 5
+    boards = _random_boards(rng, n)
+    eng = Batched2048(n, seed=seed, rng="numpy")
+    ob = OracleBatch(n, seed)
+    ob.seed_numpy(seed)
+    eng.set_boards(boards)
+    want = boards.copy()
+    for _ in range(3):
+        eng.add_tile(0)
+        for i in range(n):
+            M = _values(want[i])
+            if (want[i] == 0).any() and lib.g2048o_add_tile_numpy(M, ob.rng[i].ctypes.data) >= 0:
+                want[i] = _exps(M)
+        assert np.array_equal(eng.get_boards().reshape(n, 16), want)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)      # full boards consumed nothing
+
+
+def test_set_scores_set_clock_round_trips(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed = 3000, 8
+    eng, ora = Batched2048(n, seed=seed), OracleBatch(n, seed, threads=0)
+    eng.reset()
+    ora.reset()
+    for _ in range(9):
+        eng.step(None)
+        ora.step(None)
+    rng = np.random.default_rng(0)
+    scores = rng.integers(0, 1 << 24, n).astype(np.int32)
+    scores[:4] = (0, 1, (1 << 24) - 1, 3)                      # odd values and both ends of the range
+    eng.set_scores(scores)                                     # host array
+    ora.score[:] = scores
+    assert np.array_equal(eng.get_scores(), scores) and np.array_equal(eng.get_boards().reshape(n, 16), ora.boards)
+    eng.set_scores(torch.as_tensor(scores[::-1].copy()).to(eng.device))   # device tensor
+    assert np.array_equal(eng.scores().cpu().numpy(), scores[::-1])
+    scores[2] = 12345                                          # (play on below: stay clear of the 2^24 wrap)
+    eng.set_scores(scores)
+    ora.score[:] = scores
+    with pytest.raises(Exception):
+        eng.set_scores(np.full(n, 1 << 24, np.int32))          # outside the 24-bit score range
+    # set_boards keeps the scores (game2048_env.py:286-288)
+    eng.set_boards(ora.boards[::-1].copy())
+    assert np.array_equal(eng.get_scores(), scores)
+    eng.set_boards(ora.boards)
+    # jump the clock on both sides and keep playing: the spawn stream is a pure function of (seed, t, board)
+    eng.set_clock(1 << 33)
+    ora.t = 1 << 33
+    assert eng.clock == 1 << 33
+    for _ in range(12):
+        eng.step(None)
+        ora.step(None)
+        assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards)
+        assert np.array_equal(eng.get_scores(), ora.score)
+    assert eng.clock == (1 << 33) + 12
+
+
+def test_rollout_writes_terminal_boards(torch_cuda):
+    """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
+    episode and holds the board the episode ended on."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, k, seed = 5000, 30, 4
+    eng, ora = Batched2048(n, seed=seed), OracleBatch(n, seed, threads=0)
+    eng.reset()
+    ora.reset()
+    acts = eng.random_actions(k)
+    term = torch.zeros((k, n), dtype=torch.uint8, device=eng.device)
+    tb = torch.full((k, n, 16), 0xEE, dtype=torch.uint8, device=eng.device)
+    eng.rollout(acts, terminated=term, terminal_boards=tb)
+    tb_h, term_h = tb.cpu().numpy(), term.cpu().numpy()
+    for j in range(k):
+        ora.step(None)
+        done = ora.terminated.astype(bool)
+        assert np.array_equal(term_h[j], ora.terminated)
+        assert np.array_equal(tb_h[j][done], ora.terminal_boards[done])
+        assert (tb_h[j][~done] == 0xEE).all()                  # untouched where the episode goes on
+    with pytest.raises(Exception):
+        eng.rollout(acts, terminal_boards=tb, fused=True)
+
+
+def test_fill_random_actions_walks_the_step_axis_in_slabs(torch_cuda):
+    """More than 32 768 steps: the launcher splits gridDim.y (g2048_kernels.hip launch_fill_actions)."""
+    from gym2048_amd.batched import Batched2048
+    from oracle.cpu_ref import random_actions_np
+    n, k, seed, off = 8, 70001, 6, 12345
+    eng = Batched2048(n, seed=seed, board_offset=off)
+    a = eng.random_actions(k, t_first=5).cpu().numpy()
+    assert a.shape == (k, n)
+    for j in (0, 1, 32767, 32768, 32769, 65535, 65536, 70000):
+        assert np.array_equal(a[j], random_actions_np(seed, 5 + j, off, n)), j
+
+
+def test_canonicalize_vs_reference_table_and_oracle(torch_cuda):
+    from gym2048_amd.transitions import canonicalize_device
+    from oracle.cpu_ref import canonicalize
+    c = load_golden("canonical_table")
+    b, nb, a, sym = canonicalize_device(c["boards"], c["actions"], c["next_boards"])
+    assert np.array_equal(sym, c["symmetry"]) and np.array_equal(a, c["canon_actions"])
+    assert np.array_equal(b, c["canon_boards"]) and np.array_equal(nb, c["canon_next"])
+    # idempotent; boards only
+    b2, _, _, sym2 = canonicalize_device(b)
+    assert np.array_equal(b2, b) and not sym2.any()
+    rng = np.random.default_rng(1)
+    boards = _random_boards(rng, 20000)
+    got, _, acts, sym = canonicalize_device(boards, rng.integers(0, 4, 20000))
+    for i in range(0, 20000, 97):
+        wb, _, _, wv = canonicalize(boards[i].reshape(4, 4))
+        assert wv == sym[i] and np.array_equal(wb.reshape(16), got[i])
+
+
+def test_collective_behind_the_c_abi_one_rank(torch_cuda):
+    """g2048_comm_* / g2048_allgather_returns with RCCL loaded by the library itself: a one-rank communicator
+    (the degenerate case a 1-GPU box can run) gathers the engine's returns; the single-process multi-engine
+    form with one engine does the same."""
+    torch = torch_cuda
+    from gym2048_amd import _lib
+    from gym2048_amd.batched import Batched2048
+    lib = _lib.load()
+    n = 1 << 16
+    eng = Batched2048(n, seed=3)
+    eng.reset()
+    eng.rollout(64)
+    want = eng.get_last_scores()
+    assert (want > 0).any()
+    ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(lib.g2048_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(lib.g2048_comm_create(1, 0, ident, 0, C.byref(comm)))
+    out = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    stream = C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    _lib.check(lib.g2048_allgather_returns(eng._h, comm, out.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    _lib.check(lib.g2048_comm_destroy(comm))
+    out2 = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    engines = (C.c_void_p * 1)(eng._h)
+    outs = (C.c_void_p * 1)(out2.data_ptr())
+    _lib.check(lib.g2048_allgather_returns_local(engines, 1, outs, None))
+    assert np.array_equal(out2.cpu().numpy(), want)
+    assert lib.g2048_comm_create(2, 5, ident, 0, C.byref(comm)) != 0     # rank out of range

@@ -1,0 +1,167 @@
+"""GPU: every BASELINE.json configuration at its REAL size against the oracle, through the C ABI.
+
+  configs[1]  65 536 boards, random policy          -> tests/test_gpu_parity.py::test_random_rollout_vs_oracle
+  configs[2]  2^20 boards, random policy            -> test_full_batch_2p20_random_policy_vs_oracle (full batch)
+              + a legality-aware greedy policy (deep states: big tiles, full-board endings)
+  configs[3]  shards of one batch on several ranks  -> test_two_rank_hip_shards_allgather (2 processes, gloo, cuda:0)
+  configs[4]  2^20 boards driving a torch policy    -> test_policy_loop_2p20_zero_copy_vs_oracle
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compare_state(eng, ora, step, fields=("boards", "score")):
+    if "boards" in fields:
+        assert np.array_equal(eng.get_boards().reshape(eng.n_envs, 16), ora.boards), f"boards differ at step {step}"
+    if "score" in fields:
+        assert np.array_equal(eng.get_scores(), ora.score), f"scores differ at step {step}"
+
+
+def test_full_batch_2p20_random_policy_vs_oracle(torch_cuda):
+    """BASELINE configs[2] at its real size: 2^20 boards x 40 steps of the synthetic random policy, the WHOLE
+    batch bit for bit against the C oracle (all host cores) -- boards, scores, rewards, flags, every step."""
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, steps = 1 << 20, 42, 40
+    eng, ora = Batched2048(n, seed=seed), OracleBatch(n, seed, threads=0)
+    eng.reset()
+    ora.reset()
+    _compare_state(eng, ora, -1)
+    for s in range(steps):
+        eng.step(None)
+        ora.step(None)
+        assert np.array_equal(eng.reward.cpu().numpy(), ora.reward), s
+        assert np.array_equal(eng.terminated.cpu().numpy(), ora.terminated), s
+        assert np.array_equal(eng.illegal.cpu().numpy(), ora.illegal), s
+        assert np.array_equal(eng.highest.cpu().numpy(), ora.highest), s
+        _compare_state(eng, ora, s)
+    assert np.array_equal(eng.get_last_scores(), ora.last_score)
+    st = eng.episode_stats()
+    assert st["episodes"] == int(ora.ep_count.sum()) > n
+
+
+def _greedy_actions(torch, eng):
+    """Legality-aware greedy policy, computed on the device with trial moves (game2048_env.py:194-241,
+    trial=True): the legal direction with the largest merge score, lowest direction on ties; 0 if none."""
+    n = eng.n_envs
+    best = torch.full((n,), -1, dtype=torch.int32, device=eng.device)
+    choice = torch.zeros(n, dtype=torch.uint8, device=eng.device)
+    for d in range(4):
+        score, legal = eng.move(torch.full((n,), d, dtype=torch.uint8, device=eng.device), trial=True)
+        val = torch.where(legal.bool(), score, torch.full_like(score, -1))
+        better = val > best
+        choice = torch.where(better, torch.full_like(choice, d), choice)
+        best = torch.where(better, val, best)
+    return choice
+
+
+def test_full_batch_2p20_greedy_policy_vs_oracle(torch_cuda):
+    """2^20 boards x 256 steps of a legality-aware greedy policy: no illegal moves, so episodes run until the
+    board is full and stuck (game2048_env.py:262-280) and tiles grow to 2^8 and beyond -- spawn on nearly
+    full boards, isend at depth, reset slot selection after a LEGAL move, scores in the thousands.  Whole
+    batch against the oracle: rewards and flags every step, boards and scores every 16 steps."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, steps = 1 << 20, 7, 256
+    eng, ora = Batched2048(n, seed=seed, illegal_move_reward=-1.0), OracleBatch(n, seed, threads=0)
+    ora.illegal_move_reward = -1.0
+    eng.reset()
+    ora.reset()
+    natural_ends = 0
+    for s in range(steps):
+        acts = _greedy_actions(torch, eng)
+        eng.step(acts)
+        ora.step(acts.cpu().numpy())
+        assert np.array_equal(eng.reward.cpu().numpy(), ora.reward), s
+        assert np.array_equal(eng.terminated.cpu().numpy(), ora.terminated), s
+        assert not ora.illegal.any(), "a legality-aware policy never makes an illegal move"
+        natural_ends += int(ora.terminated.sum())
+        if s % 16 == 15 or s == steps - 1:
+            _compare_state(eng, ora, s)
+            assert np.array_equal(eng.highest.cpu().numpy(), ora.highest), s
+    assert np.array_equal(eng.get_last_scores(), ora.last_score)
+    st = eng.episode_stats()
+    assert st["episodes"] == natural_ends == int(ora.ep_count.sum()) and st["illegal_ends"] == 0
+    assert natural_ends > n // 4, "hundreds of thousands of whole games played to a full, stuck board"
+    assert st["max_exp"] >= 8 and st["last_score_max"] >= 2000, (st["max_exp"], st["last_score_max"])
+
+
+def test_policy_loop_2p20_zero_copy_vs_oracle(torch_cuda):
+    """BASELINE configs[4]: 2^20 boards driving a torch policy on the same GPU with zero host copies --
+    g2048_onehot writes the (N,16,4,4) float16 observation INTO a caller-owned torch tensor, a small conv
+    net (the shape of ppo_train.py:36-62: conv3x3 16->C, ReLU, flatten, linear -> 4 logits) picks argmax
+    actions (int64), g2048_step reads that tensor's memory.  The int64 actions are copied out afterwards and
+    the whole batch is replayed on the oracle."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, steps = 1 << 20, 11, 12
+    eng, ora = Batched2048(n, seed=seed), OracleBatch(n, seed, threads=0)
+    eng.reset()
+    ora.reset()
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")      # no exhaustive kernel search for a test
+    torch.manual_seed(0)
+    dev = eng.device
+    conv = torch.nn.Conv2d(16, 8, 3, padding=1).to(dev).half()
+    head = torch.nn.Linear(8 * 16, 4).to(dev).half()
+    obs = torch.empty((n, 16, 4, 4), dtype=torch.float16, device=dev)
+    actions = torch.empty(n, dtype=torch.int64, device=dev)    # what argmax produces; reused every step
+    obs_ptr, act_ptr = obs.data_ptr(), actions.data_ptr()
+    all_actions = torch.empty((steps, n), dtype=torch.int64, device=dev)
+    chunk = 1 << 17                                            # the policy's forward batch (as bench_policy.py)
+    with torch.no_grad():
+        for s in range(steps):
+            out = eng.observe_onehot(out=obs)
+            assert out is obs and obs.data_ptr() == obs_ptr            # written in place, no new buffer
+            for lo in range(0, n, chunk):
+                logits = head(torch.relu(conv(obs[lo:lo + chunk])).flatten(1))
+                actions[lo:lo + chunk] = logits.argmax(dim=1)            # int64, on the device
+            assert actions.data_ptr() == act_ptr and eng._as_device(actions) is actions   # step() gets THIS memory
+            eng.step(actions)
+            all_actions[s] = actions
+    torch.cuda.synchronize()
+    # the observation the policy saw last is the one-hot of the boards before the last step: check a strided
+    # sample of it against the oracle's stack() after replaying steps - 1 steps
+    host_actions = all_actions.cpu().numpy()
+    assert len(np.unique(host_actions)) > 1, "the policy should not be constant"
+    for s in range(steps):
+        if s == steps - 1:
+            sample = np.arange(0, n, 4099)
+            want = ora.onehot()[sample]
+            assert np.array_equal(obs[torch.as_tensor(sample, device=dev)].cpu().numpy(), want.astype(np.float16))
+        ora.step((host_actions[s] & 3).astype(np.uint8))
+    _compare_state(eng, ora, steps)
+    assert np.array_equal(eng.reward.cpu().numpy(), ora.reward)
+    assert np.array_equal(eng.terminated.cpu().numpy(), ora.terminated)
+    assert np.array_equal(eng.get_last_scores(), ora.last_score)
+
+
+def test_two_rank_hip_shards_allgather(torch_cuda, tmp_path):
+    """BASELINE configs[3]'s code path on one GPU: two processes (torch.distributed over gloo, both on
+    cuda:0), each a HIP Batched2048 shard with its board_offset; the all-gathered episodic returns and
+    the concatenated shard boards equal a single engine holding the whole batch."""
+    from gym2048_amd.batched import Batched2048
+    n, seed, k = 1 << 17, 42, 48
+    port = 29500 + os.getpid() % 2000
+    out = tmp_path / "gathered.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_hip_worker.py"), str(n), str(seed), str(k),
+                               str(out)], env=dict(env, RANK=str(r)), cwd=ROOT) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    whole = Batched2048(n, seed=seed)
+    whole.reset()
+    whole.rollout(k)
+    got = np.load(out)
+    assert np.array_equal(got["returns"], whole.get_last_scores())
+    assert np.array_equal(got["boards"], whole.get_boards().reshape(n, 16))
+    assert int(got["episodes"]) == whole.episode_stats()["episodes"]

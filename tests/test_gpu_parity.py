@@ -8,15 +8,6 @@ from conftest import TRAJECTORIES, load_golden, replay_trajectory
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
-    import __graft_entry__ as ge
-    ge.build()
-    return torch
-
-
 class GpuBatch:
     """OracleBatch-shaped facade over Batched2048 so the same replay helper drives both."""
 

@@ -242,3 +242,66 @@ def test_shard_arithmetic():
     assert (s.offset, s.n_local, s.n_global) == (5 << 20, 1 << 20, 1 << 23)
     with pytest.raises(ValueError):
         shard_range(4, 4, 4)
+
+
+def test_drop_ins_take_gymnasium_and_sb3_base_classes_when_present(monkeypatch):
+    """``gym.make('2048-v0')`` needs a ``gymnasium.Env``, ``PPO(env=...)`` a ``VecEnv`` (ppo_train.py:102,123):
+    the base classes are chosen at import time.  gymnasium / SB3 are not installed in this image, so minimal
+    stand-ins are put in ``sys.modules`` and the two modules re-imported."""
+    import importlib
+    import sys
+    import types
+
+    gym = types.ModuleType("gymnasium")
+
+    class Env:
+        def reset(self, *, seed=None, options=None):
+            self.seeded_with = seed
+
+    spaces = types.ModuleType("gymnasium.spaces")
+    spaces.Discrete = lambda n: ("Discrete", n)
+    spaces.Box = lambda lo, hi, shape, dtype=None: ("Box", shape)
+    gym.Env, gym.spaces = Env, spaces
+    sb3 = types.ModuleType("stable_baselines3")
+    common = types.ModuleType("stable_baselines3.common")
+    vec = types.ModuleType("stable_baselines3.common.vec_env")
+
+    class VecEnv:
+        def __init__(self, num_envs, observation_space, action_space):
+            self.init_args = (num_envs, observation_space, action_space)
+
+    vec.VecEnv = VecEnv
+    for name, mod in (("gymnasium", gym), ("gymnasium.spaces", spaces), ("stable_baselines3", sb3),
+                      ("stable_baselines3.common", common), ("stable_baselines3.common.vec_env", vec)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    import gym2048_amd.env as env_mod
+    import gym2048_amd.vec_env as vec_mod
+    try:
+        env_mod = importlib.reload(env_mod)
+        vec_mod = importlib.reload(vec_mod)
+        assert issubclass(env_mod.Game2048Env, Env) and issubclass(vec_mod.Vec2048, VecEnv)
+        e = env_mod.Game2048Env(engine=OracleEngine(1, 3))
+        obs, info = e.reset(seed=5)
+        assert e.seeded_with == 5 and obs.shape == (16, 4, 4) and info == {}
+        assert e.action_space == ("Discrete", 4) and e.observation_space == ("Box", (16, 4, 4))
+        v = vec_mod.Vec2048(8, engine=OracleEngine(8, 3))
+        assert v.init_args[0] == 8 and v.num_envs == 8 and v.reset().shape == (8, 16, 4, 4)
+    finally:
+        for name in ("gymnasium", "gymnasium.spaces", "stable_baselines3", "stable_baselines3.common",
+                     "stable_baselines3.common.vec_env"):
+            monkeypatch.delitem(sys.modules, name, raising=False)
+        importlib.reload(env_mod)
+        importlib.reload(vec_mod)
+    assert env_mod.Game2048Env.__mro__[1] is object
+
+
+def test_real_gymnasium_and_sb3_accept_the_drop_ins():
+    """With the real packages installed: gym.make('2048-v0') returns our env, SB3 keeps Vec2048 as is."""
+    gymnasium = pytest.importorskip("gymnasium")
+    import gym2048_amd
+    gym2048_amd.register(entry_point=lambda **kw: gym2048_amd.Game2048Env(engine=OracleEngine(1, 3), **kw))
+    env = gymnasium.make("2048-v0")
+    assert isinstance(env.unwrapped, gym2048_amd.Game2048Env)
+    pytest.importorskip("stable_baselines3")
+    from stable_baselines3.common.vec_env import VecEnv
+    assert isinstance(gym2048_amd.Vec2048(4, engine=OracleEngine(4, 3)), VecEnv)

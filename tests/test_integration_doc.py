@@ -10,10 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_integration_md_stub_runs_and_matches_engine():
-    import torch
+def test_integration_md_stub_runs_and_matches_engine(torch_cuda):
+    torch = torch_cuda
     import __graft_entry__ as ge
-    ge.build_hip()
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     code = re.search(r"```python\n(import ctypes as C.*?)```", text, re.S).group(1)
     code = code.replace('C.CDLL("libg2048_hip.so")', f'C.CDLL({ge.HIP_LIB!r})')

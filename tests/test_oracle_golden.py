@@ -183,3 +183,26 @@ def test_oracle_threads_and_reset_slots():
     e.slot = 3
     e.reset()
     assert list(cpu_ref.values_to_exp(e.M)) == list(c.boards[2])
+
+
+def test_canonicalisation_oracle_matches_the_reference_symmetries():
+    """oracle.cpu_ref.canonicalize (np.flip / np.rot90 restated) == the table built with the reference's own
+    training_data.hflip()/rotate() (tests/golden/canonical_table.npz)."""
+    from oracle.cpu_ref import canonicalize
+    c = load_golden("canonical_table")
+    for i in range(len(c["boards"])):
+        b, a, nb, v = canonicalize(c["boards"][i].reshape(4, 4), int(c["actions"][i]), c["next_boards"][i].reshape(4, 4))
+        assert v == c["symmetry"][i] and a == c["canon_actions"][i]
+        assert np.array_equal(b.reshape(16), c["canon_boards"][i]) and np.array_equal(nb.reshape(16), c["canon_next"][i])
+    assert len(np.unique(c["symmetry"])) == 8
+
+
+def test_render_ansi_matches_the_reference_text():
+    """render('ansi') text (game2048_env.py:156-163): 'Score: 0' before the first legal move (int), floats
+    afterwards; numpy's grid formatting incl. wide tiles."""
+    from gym2048_amd.render import render_board
+    r = load_golden("render_ansi")
+    for e, score, is_int, text in zip(r["boards"], r["scores"], r["score_is_int"], r["texts"]):
+        vals = np.where(e > 0, 1 << e.astype(np.int64), 0).reshape(4, 4)
+        got = render_board(vals, int(score) if is_int else float(score), "ansi").getvalue()
+        assert got == str(text)

@@ -45,7 +45,7 @@ def test_unstack_inverts_stack():
 
 
 @pytest.mark.gpu
-def test_device_augment_matches_reference_augment():
+def test_device_augment_matches_reference_augment(torch_cuda):
     d, t = fixture_transitions()
     a = t.augment()
     assert a.size() == 8 * t.size()
@@ -55,7 +55,7 @@ def test_device_augment_matches_reference_augment():
 
 
 @pytest.mark.gpu
-def test_record_rollout_transitions_are_consistent_with_the_oracle():
+def test_record_rollout_transitions_are_consistent_with_the_oracle(torch_cuda):
     import ctypes as C
 
     import oracle

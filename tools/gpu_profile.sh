@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_tcc -o r -- $B
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_DRAM_32B -d $O/pmc_rd32 -o r -- $BENCH > $O/pmc_rd32.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_WRITE_DRAM_32B -d $O/pmc_wr32 -o r -- $BENCH > $O/pmc_wr32.log 2>&1
 python tools/rocpd_summary.py $O/stats/r_results.db $O/pmc_sq1/r_results.db $O/pmc_sq2/r_results.db $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_tcc/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > $O/summary.txt 2>&1
-python tools/rocpd_summary.py --traffic-json $O/traffic.json $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > /dev/null 2>&1
+python tools/rocpd_summary.py --traffic-json $O/traffic.json --profile-tag $TAG --csrc-hash $(python -c "import bench; print(bench.csrc_hash())") $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > /dev/null 2>&1
 grep -h '"metric"' $O/stats.log > $O/bench_under_rocprof.json
 rm -rf $O/*/r_results.db   # keep the merged gpurun_out small; the summary is what gets committed
 cat $O/summary.txt

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--kernel", default="step_kernel")
     ap.add_argument("--traffic-json", default=None,
                     help="write HBM bytes per launch of --kernel from FETCH_SIZE/WRITE_SIZE (+ DRAM_32B cross-check)")
+    ap.add_argument("--profile-tag", default=None, help="name of the profile the traffic file belongs to")
+    ap.add_argument("--csrc-hash", default=None, help="bench.csrc_hash() of the sources that were profiled")
     args = ap.parse_args()
     collected = {}
     for path in args.dbs:
@@ -55,7 +57,8 @@ def main():
         # gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KB) is exact; *_DRAM_32B x 32 B are exact.
         rd = collected["FETCH_SIZE"] * 1024 * 2
         wr = collected["WRITE_SIZE"] * 1024
-        out = {"kernel": args.kernel, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+        out = {"kernel": args.kernel, "profile": args.profile_tag, "csrc_sha16": args.csrc_hash,
+               "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                "bytes_per_launch": rd + wr,
                "method": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes"}
         if "TCC_EA0_RDREQ_DRAM_32B" in collected and "TCC_EA0_WRREQ_WRITE_DRAM_32B" in collected:

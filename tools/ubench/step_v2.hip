@@ -20,6 +20,129 @@
 
 struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 
+// ---- experiment copy of step_kernel (same device functions) with I/O switches
+enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
+       X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
+       X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768 };
+
+template <int X>
+__global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
+{
+    using namespace g2048;
+    __shared__ WaveTables s_tables[4];
+    const uint32_t i_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
+    const uint32_t lane = threadIdx.x & 63u;
+    Board rec = load_board_nt(p.st.boards, i);
+    const uint32_t lut_word = load_move_lut_word();
+    // lanes 0,1 of the block touch the NEXT step's 256 action bytes of this block (one dword per 128-byte
+    // line), issued with the board load: the line is in the Infinity Cache when the next launch wants it
+    uint32_t touched = 0;
+    if ((X & X_PREFETCH) && threadIdx.x < 2u)
+        touched = *(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p.actions) + p.n + (size_t)blockIdx.x * 256u) + threadIdx.x * 32u);
+    // the wave's counter pair through the scalar cache (uniform address)
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(i_raw >> 6);
+    unsigned long long old_ep = 0, old_ill = 0;
+    if (X & (X_COUNT_SLOAD | X_LASTREC_RING)) {
+        const unsigned long long *c = p.st.ep_counters + 2u * wave_id;
+        old_ep = c[0];
+        old_ill = c[1];
+    }
+    uint32_t packed_actions = 0;
+    if ((X & X_ACT_PACKED) && lane < 16u)
+        packed_actions = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p.actions) + (i_raw & ~63u)) + lane);
+    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+    uint32_t action;
+    if (X & X_NO_ACT)
+        action = w.w[3] >> 30;
+    else if (X & X_ACT_PACKED) {
+        const uint32_t d = __builtin_amdgcn_ds_bpermute((lane >> 2) << 2, packed_actions); // dword of lane / 4
+        action = (d >> (8u * (lane & 3u))) & 3u;
+    } else
+        action = load_action<1>(p.actions, i, 0u);
+    const LdsTables tb = stage_tables(s_tables, use_after(lut_word, w.w[0]));
+    const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
+    if (valid) {
+        store_board_nt(p.st.boards, i, rec);
+        if (!(X & X_NO_REWARD)) {
+            if (X & X_REWARD_U16)
+                __builtin_nontemporal_store(static_cast<uint16_t>(o.gain), reinterpret_cast<uint16_t *>(p.reward) + i);
+            else
+                __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + i);
+        }
+        if (!(X & (X_NO_TERM | X_TERM_PACKED)))
+            __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
+    }
+    if (X & X_TERM_PACKED) {
+        const unsigned long long m = __ballot(o.terminated);
+        if (lane < 16u) {
+            const uint32_t nib = static_cast<uint32_t>(m >> (4u * lane)) & 0xfu;
+            const uint32_t bytes = (nib * 0x00204081u) & 0x01010101u;
+            __builtin_nontemporal_store(bytes, reinterpret_cast<uint32_t *>(p.terminated + (i_raw & ~63u)) + lane);
+        }
+    }
+    uint32_t episodes = 0, illegal_ends = 0;
+    if ((X & X_PREFETCH) && touched == 0x12345677u)
+        p.st.ep_counters[0] = touched; // keeps the touch alive
+    if (X & (X_LASTREC_DENSE | X_LASTREC_4B | X_LASTREC_RING)) {
+        const bool fin = o.terminated && valid;
+        const unsigned long long done = __ballot(fin);
+        if (done) {
+            if (fin) {
+                const uint4 v = make_uint4(o.terminal.r[0], o.terminal.r[1], o.terminal.r[2], o.terminal.r[3]);
+                if (X & X_LASTREC_4B)
+                    reinterpret_cast<uint32_t *>(p.st.last_record)[i] = v.x;      // one dword, board-indexed (sparse)
+                else if (X & X_LASTREC_RING) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done, 0u));
+                    const uint32_t slot = ((uint32_t)old_ep + rank) & 63u;
+                    p.st.last_record[(size_t)wave_id * 64u + slot] = make_uint4(v.x | (lane << 5 & 0xe0u) | ((lane >> 3) << 13), v.y, v.z, v.w);
+                } else
+                    p.st.last_record[(size_t)(i & ~63u) + (lane & 7u)] = v;       // dense dummy: 8 slots per wave (memory-effect probe)
+            }
+            episodes += (uint32_t)__popcll(done);
+            illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
+        }
+    } else if (X & (X_LASTREC_32 | X_LASTREC_64)) {
+        const bool fin = o.terminated && valid;
+        const unsigned long long done = __ballot(fin);
+        if (done) {
+            if (fin) {
+                constexpr uint32_t STRIDE = (X & X_LASTREC_64) ? 4 : 2;
+                uint4 *dst = p.st.last_record + (size_t)i * STRIDE;
+                const uint4 v = make_uint4(o.terminal.r[0], o.terminal.r[1], o.terminal.r[2], o.terminal.r[3]);
+                for (uint32_t q = 0; q < STRIDE; ++q)
+                    dst[q] = v;
+            }
+            episodes += (uint32_t)__popcll(done);
+            illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
+        }
+    } else if (!(X & X_NO_LASTREC))
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
+    if (X & (X_COUNT_SLOAD | X_LASTREC_RING)) {
+        if (episodes != 0u && lane == 0u) {
+            ulonglong2 *c = reinterpret_cast<ulonglong2 *>(p.st.ep_counters + 2u * wave_id);
+            ulonglong2 v;
+            v.x = old_ep + episodes; v.y = old_ill + illegal_ends;
+            *c = v;
+        }
+    } else if (X & X_COUNT_RMW) {
+        if (episodes != 0u && lane == 0u) {
+            ulonglong2 *c = reinterpret_cast<ulonglong2 *>(p.st.ep_counters + 2u * (i_raw >> 6));
+            ulonglong2 v = *c;
+            v.x += episodes; v.y += illegal_ends;
+            *c = v;
+        }
+    } else if (!(X & X_NO_COUNT))
+        flush_episode_counts(p, i_raw, episodes, illegal_ends);
+}
+
+template <int X>
+static void launch_x(const g2048::StepArgs &a)
+{
+    hipLaunchKernelGGL((kern_x<X>), dim3((a.n + 255) / 256), dim3(256), 0, 0, a);
+}
+
 int main(int argc, char **argv)
 {
     const int lg = argc > 1 ? atoi(argv[1]) : 20;
@@ -39,12 +162,12 @@ int main(int argc, char **argv)
     // ---- v2 state
     g2048::StepArgs a2{};
     CHECK(hipMalloc(&a2.st.boards, (size_t)n * 16));
-    CHECK(hipMalloc(&a2.st.last_record, (size_t)n * 16));
+    CHECK(hipMalloc(&a2.st.last_record, (size_t)n * 64));
     CHECK(hipMalloc(&a2.st.ep_counters, (size_t)(n / 64 + 16) * 16));
     CHECK(hipMemset(a2.st.last_record, 0, (size_t)n * 16));
     CHECK(hipMemset(a2.st.ep_counters, 0, (size_t)(n / 64 + 16) * 16));
     uint8_t *actions, *term; float *reward;
-    CHECK(hipMalloc(&actions, (size_t)n * launches));
+    CHECK(hipMalloc(&actions, (size_t)n * (launches + 1)));
     CHECK(hipMalloc(&term, (size_t)n * launches));
     CHECK(hipMalloc(&reward, (size_t)n * launches * 4));
     CHECK(hipMemset(term, 0, (size_t)n * launches));
@@ -90,6 +213,27 @@ int main(int argc, char **argv)
     vs.push_back({"v3  product step_kernel<0> (synthetic actions)", [&](uint32_t j) { io2(j); (void)g2048::launch_step(a2, 0, 0); }});
     vs.push_back({"v3  step_kernel<1>, no outputs", [&](uint32_t j) { io2(j); a2.reward = nullptr; a2.terminated = nullptr; (void)g2048::launch_step(a2, 1, 0); }});
 
+    vs.push_back({"x   copy of the product kernel (sanity: = v3 <1>)", [&](uint32_t j) { io2(j); launch_x<0>(a2); }});
+    vs.push_back({"x   actions: 16 lanes load a dword, ds_bpermute", [&](uint32_t j) { io2(j); launch_x<X_ACT_PACKED>(a2); }});
+    vs.push_back({"x   terminated: ballot -> 16 lanes store a dword", [&](uint32_t j) { io2(j); launch_x<X_TERM_PACKED>(a2); }});
+    vs.push_back({"x   both packed", [&](uint32_t j) { io2(j); launch_x<X_ACT_PACKED | X_TERM_PACKED>(a2); }});
+    vs.push_back({"x   no reward store", [&](uint32_t j) { io2(j); launch_x<X_NO_REWARD>(a2); }});
+    vs.push_back({"x   no terminated store", [&](uint32_t j) { io2(j); launch_x<X_NO_TERM>(a2); }});
+    vs.push_back({"x   no action load (synthetic)", [&](uint32_t j) { io2(j); launch_x<X_NO_ACT>(a2); }});
+    vs.push_back({"x   no last_record store, no counters", [&](uint32_t j) { io2(j); launch_x<X_NO_LASTREC | X_NO_COUNT>(a2); }});
+    vs.push_back({"x   no counters (atomics)", [&](uint32_t j) { io2(j); launch_x<X_NO_COUNT>(a2); }});
+    vs.push_back({"x   reward stored as u16 (not the ABI; traffic probe)", [&](uint32_t j) { io2(j); launch_x<X_REWARD_U16>(a2); }});
+    vs.push_back({"x   counters: plain load-add-store by lane 0 (late load)", [&](uint32_t j) { io2(j); launch_x<X_COUNT_RMW>(a2); }});
+    vs.push_back({"x   last_record 32 B per board (full-sector store)", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_32>(a2); }});
+    vs.push_back({"x   last_record 64 B per board", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_64>(a2); }});
+    vs.push_back({"x   lanes 0,1 of each block touch the next step's actions", [&](uint32_t j) { io2(j); launch_x<X_PREFETCH>(a2); }});
+    vs.push_back({"x   counters: scalar load early, lane-0 store late", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD>(a2); }});
+    vs.push_back({"x   last_record store to a dense dummy slot (memory-effect probe)", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_DENSE>(a2); }});
+    vs.push_back({"x   last_record store of ONE dword, board-indexed", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_4B>(a2); }});
+    vs.push_back({"x   per-wave ring of terminal records (cursor = episode count) + scalar counters", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_RING>(a2); }});
+    vs.push_back({"x   ring + scalar counters + action touch", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_RING | X_PREFETCH>(a2); }});
+    vs.push_back({"x   scalar counters + action touch", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD | X_PREFETCH>(a2); }});
+
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<std::vector<float>> us(vs.size());
@@ -102,6 +246,52 @@ int main(int argc, char **argv)
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (r > 0) us[v].push_back(ms * 1e3f / launches);
         }
+    }
+    // ---- the same 64 launches of the product kernel replayed as ONE hipGraph (is the dependent-kernel
+    //      boundary any shorter?) and split over two streams (halves of the batch leapfrogging)
+    {
+        hipStream_t cs, s2;
+        CHECK(hipStreamCreate(&cs)); CHECK(hipStreamCreate(&s2));
+        hipGraph_t graph; hipGraphExec_t exec;
+        CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal));
+        for (int j = 0; j < launches; ++j) { io2(j); CHECK(g2048::launch_step(a2, 1, cs)); }
+        CHECK(hipStreamEndCapture(cs, &graph));
+        CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        std::vector<float> g_us, t_us;
+        for (int r = 0; r < rounds + 1; ++r) {
+            CHECK(hipEventRecord(e0, cs));
+            CHECK(hipGraphLaunch(exec, cs));
+            CHECK(hipEventRecord(e1, cs));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) g_us.push_back(ms * 1e3f / launches);
+        }
+        // two streams: boards [0, n/2) on cs, [n/2, n) on s2, each its own chain of launches
+        g2048::StepArgs lo = a2, hi = a2;
+        lo.n = hi.n = n / 2; hi.board_offset = n / 2;
+        hi.st.boards = a2.st.boards + n / 2; hi.st.last_record = a2.st.last_record + n / 2; hi.st.ep_counters = a2.st.ep_counters + n / 64;
+        hipEvent_t f0, f1; CHECK(hipEventCreate(&f0)); CHECK(hipEventCreate(&f1));
+        for (int r = 0; r < rounds + 1; ++r) {
+            CHECK(hipEventRecord(e0, cs));
+            CHECK(hipStreamWaitEvent(s2, e0, 0));
+            for (int j = 0; j < launches; ++j) {
+                lo.t_lo = hi.t_lo = 100 + j;
+                lo.actions = actions + (size_t)j * n; hi.actions = actions + (size_t)j * n + n / 2;
+                lo.reward = reward + (size_t)j * n; hi.reward = reward + (size_t)j * n + n / 2;
+                lo.terminated = term + (size_t)j * n; hi.terminated = term + (size_t)j * n + n / 2;
+                CHECK(g2048::launch_step(lo, 1, cs));
+                CHECK(g2048::launch_step(hi, 1, s2));
+            }
+            CHECK(hipEventRecord(f1, s2));
+            CHECK(hipStreamWaitEvent(cs, f1, 0));
+            CHECK(hipEventRecord(e1, cs));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) t_us.push_back(ms * 1e3f / launches);
+        }
+        std::sort(g_us.begin(), g_us.end()); std::sort(t_us.begin(), t_us.end());
+        printf("hipGraph replay of %d product launches: %.2f us per launch (median), %.2f (min)\n", launches, g_us[g_us.size() / 2], g_us[0]);
+        printf("two streams, half the batch each:        %.2f us per step   (median), %.2f (min)\n", t_us[t_us.size() / 2], t_us[0]);
     }
     printf("boards 2^%d, %d rounds x %d launches; us per launch (median, min)\n", lg, rounds, launches);
     for (size_t v = 0; v < vs.size(); ++v) {
