@@ -23,14 +23,31 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 // ---- experiment copy of step_kernel (same device functions) with I/O switches
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
-       X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768 };
+       X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
+       X_PREFETCH_BLOCKS = 65536 };
 
 template <int X>
 __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
 {
     using namespace g2048;
     __shared__ WaveTables s_tables[4];
-    const uint32_t i_raw = blockIdx.x * 256 + threadIdx.x;
+    uint32_t block = blockIdx.x;
+    if (X & X_PREFETCH_BLOCKS) {
+        // the FIRST n/32768 blocks of the grid only touch the next step's action bytes (one dword per lane,
+        // one per 128-byte line) and retire; the lines are in the Infinity Cache when the next launch reads them
+        const uint32_t pf = (p.n + 32767u) / 32768u;
+        if (block < pf) {
+            const uint32_t line = block * 256u + threadIdx.x;
+            if (line * 128u < p.n) {
+                uint32_t v;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p.actions) + p.n) + line * 32u;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+            }
+            return;
+        }
+        block -= pf;
+    }
+    const uint32_t i_raw = block * 256 + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
     const uint32_t lane = threadIdx.x & 63u;
@@ -40,11 +57,11 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     // line), issued with the board load: the line is in the Infinity Cache when the next launch wants it
     uint32_t touched = 0;
     if ((X & X_PREFETCH) && threadIdx.x < 2u)
-        touched = *(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p.actions) + p.n + (size_t)blockIdx.x * 256u) + threadIdx.x * 32u);
+        touched = *(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p.actions) + p.n + (size_t)block * 256u) + threadIdx.x * 32u);
     // the wave's counter pair through the scalar cache (uniform address)
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(i_raw >> 6);
     unsigned long long old_ep = 0, old_ill = 0;
-    if (X & (X_COUNT_SLOAD | X_LASTREC_RING)) {
+    {
         const unsigned long long *c = p.st.ep_counters + 2u * wave_id;
         old_ep = c[0];
         old_ill = c[1];
@@ -119,7 +136,7 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
         }
     } else if (!(X & X_NO_LASTREC))
         record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
-    if (X & (X_COUNT_SLOAD | X_LASTREC_RING)) {
+    if (!(X & (X_NO_COUNT | X_COUNT_RMW))) {
         if (episodes != 0u && lane == 0u) {
             ulonglong2 *c = reinterpret_cast<ulonglong2 *>(p.st.ep_counters + 2u * wave_id);
             ulonglong2 v;
@@ -133,14 +150,13 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
             v.x += episodes; v.y += illegal_ends;
             *c = v;
         }
-    } else if (!(X & X_NO_COUNT))
-        flush_episode_counts(p, i_raw, episodes, illegal_ends);
+    }
 }
 
 template <int X>
 static void launch_x(const g2048::StepArgs &a)
 {
-    hipLaunchKernelGGL((kern_x<X>), dim3((a.n + 255) / 256), dim3(256), 0, 0, a);
+    hipLaunchKernelGGL((kern_x<X>), dim3((a.n + 255) / 256 + ((X & X_PREFETCH_BLOCKS) ? (a.n + 32767) / 32768 : 0)), dim3(256), 0, 0, a);
 }
 
 int main(int argc, char **argv)
@@ -233,6 +249,8 @@ int main(int argc, char **argv)
     vs.push_back({"x   per-wave ring of terminal records (cursor = episode count) + scalar counters", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_RING>(a2); }});
     vs.push_back({"x   ring + scalar counters + action touch", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_RING | X_PREFETCH>(a2); }});
     vs.push_back({"x   scalar counters + action touch", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD | X_PREFETCH>(a2); }});
+    vs.push_back({"x   scalar counters (= product now)", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD>(a2); }});
+    vs.push_back({"x   scalar counters + prefetch blocks at the head of the grid", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD | X_PREFETCH_BLOCKS>(a2); }});
 
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
