@@ -48,6 +48,12 @@ def parse_args():
     ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip fused / streaming / cpu legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--device-warmup", type=float, default=0.25,
+                    help="seconds of GPU work on a SCRATCH engine before anything is measured (clocks at their "
+                         "sustained level, as in a long-running job); 0 disables")
+    ap.add_argument("--gather", choices=["summary", "full"], default="summary",
+                    help="N > 1: what the once-per-rollout all-gather ships -- the per-rank return summary "
+                         "(g2048_stats, 168 B) or every board's last episodic return (int32[B])")
     return ap.parse_args()
 
 
@@ -180,7 +186,7 @@ def main():
     if world > 1:
         dist.barrier()
     from gym2048_amd.batched import Batched2048
-    from gym2048_amd.sharding import weak_shard, allgather_returns
+    from gym2048_amd.sharding import weak_shard, allgather_returns, allgather_stats, merge_stats
 
     B, K, W = args.boards, args.steps, args.warmup
     shard = weak_shard(B, rank, world)
@@ -193,10 +199,28 @@ def main():
         torch.cuda.synchronize()
 
     def gather_returns():
-        local = eng.last_scores()                  # int32[B] returns, from the terminal records (one kernel)
-        if backend != "nccl" and world > 1:        # gloo smoke test: collectives on host copies
-            return allgather_returns(local.cpu(), shard)
-        return allgather_returns(local, shard)
+        """The path's only exchange, once per rollout: every rank reduces the episodic returns of its shard on
+        the device (one kernel, no host sync) and the per-rank summaries are all-gathered (RCCL over xGMI,
+        latency-bound); --gather full ships every board's last return instead (4 MiB per rank at 2^20)."""
+        if args.gather == "full":
+            local = eng.last_scores()              # int32[B] returns, from the terminal records (one kernel)
+            if backend != "nccl" and world > 1:    # gloo smoke test: collectives on host copies
+                return allgather_returns(local.cpu(), shard)
+            return allgather_returns(local, shard)
+        local = eng.episode_stats_device()
+        return allgather_stats(local.cpu() if (backend != "nccl" and world > 1) else local)
+
+    # ---- device warm-up on a scratch engine (every rank): not steps of the benchmarked engine, whose own
+    #      warm-up is exactly the W steps below
+    if args.device_warmup > 0:
+        scratch = Batched2048(B, device=local_rank, seed=SEED + 1)
+        scratch.reset()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.device_warmup:
+            scratch.rollout_random(256)
+            torch.cuda.synchronize()
+        scratch.close()
+        del scratch
 
     # ---- inputs and outputs of the timed K steps: allocated, generated and TOUCHED before any timing
     #      (a fresh box's first touch of a page must not land in the timed region), then the W untimed
@@ -215,11 +239,12 @@ def main():
             eng.rollout(wa[j0:j0 + kk], reward=wr[:kk], terminated=wt[:kk])
         del wa, wr, wt
 
+    plan = eng.prepare_rollout(actions, reward=reward, terminated=terminated)   # argument checks: not timed
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    ev0.record()                                         # on the (idle) launch stream: start of the launch train
     t0 = time.perf_counter()
-    ev0.record()
-    eng.rollout(actions, reward=reward, terminated=terminated)   # EXACTLY K step launches
+    plan.run()                                           # g2048_rollout: EXACTLY K step launches
     ev1.record()
     # the path's only exchange: once per rollout, N > 1 only (RCCL all-gather of the episodic returns)
     gathered = gather_returns() if world > 1 else None
@@ -232,7 +257,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_region_ms = float(tmax[0]), float(tmax[1])
-    assert gathered is None or gathered.numel() == B * world
+    if gathered is not None:
+        assert gathered.numel() == (B * world if args.gather == "full" else 168 * world)
 
     # sanity inside the bench: the rollout really happened (episodes finished, rewards written)
     stats = eng.episode_stats()
@@ -249,10 +275,13 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"batch={B} envs per GPU, random-policy rollout, int8 boards (BASELINE configs[2])",
                    "boards_per_gpu": B, "global_boards": B * world, "seed": SEED,
+                   "device_warmup": (f"{args.device_warmup} s of fused synthetic rollouts on a scratch engine before the "
+                                     f"W warm-up steps") if args.device_warmup > 0 else "none",
                    "path": "one step_kernel launch per env-step (g2048_rollout), actions/reward/terminated in "
                            "[K][B] HBM rollout buffers, auto-reset fused",
-                   "collective": "none per step; one all-gather of episodic returns per rollout" if world > 1
-                   else "none"},
+                   "collective": (f"none per step; one all-gather per rollout of the "
+                                  f"{'per-rank episodic-return summaries (168 B each)' if args.gather == 'summary' else 'per-board episodic returns (int32[B] each)'}"
+                                  if world > 1 else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_provenance": traffic_prov,
@@ -263,6 +292,10 @@ def main():
                               "extras.streaming_2p24 is the run that streams HBM") if B <= (1 << 22) else None},
         "episodes_finished": int(stats["episodes"]), "mean_last_episode_score": stats["mean_last_score"],
     }
+    if gathered is not None and args.gather == "summary":
+        g = merge_stats(gathered)
+        out["global_returns"] = {"episodes": g["episodes"], "mean_last_episode_score": g["mean_last_score"],
+                                 "best_last_episode_score": g["last_score_max"]}
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}

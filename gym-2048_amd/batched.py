@@ -43,6 +43,19 @@ def max_tile_to_exp(max_tile):
     return exp
 
 
+class _RolloutPlan:
+    """A validated rollout: the C struct with the buffer pointers (the tensors are kept alive here)."""
+
+    def __init__(self, engine, fn, k, io, auto_reset, keep):
+        self._engine, self._fn, self._k, self._io, self._auto_reset, self._keep = engine, fn, k, io, auto_reset, keep
+        self._io_ref = C.byref(io)
+
+    def run(self):
+        e = self._engine
+        check(self._fn(e._h, self._k, self._io_ref, e.n_envs, self._auto_reset, e._stream()))
+        e._fresh = False
+
+
 class Batched2048:
     """``n_envs`` boards resident on ``cuda:device``; the batched counterpart of ``Game2048Env``.
 
@@ -204,6 +217,12 @@ class Batched2048:
         the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers (``terminal_boards``:
         ``[k, n, 16]``, rows written only where an episode ended; not with ``fused``).  ``fused=True`` runs
         them as ONE launch with the boards in registers (same outputs, ``g2048_rollout_fused``)."""
+        self.prepare_rollout(actions, reward, terminated, illegal, highest, auto_reset, fused, terminal_boards).run()
+
+    def prepare_rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None,
+                        auto_reset: bool = True, fused: bool = False, terminal_boards=None):
+        """Validate the buffers of a rollout and build its launch descriptor once; ``.run()`` then is a
+        single call into ``g2048_rollout`` (the argument checks stay out of a latency-critical loop)."""
         if isinstance(actions, int):
             k, act = actions, None
         else:
@@ -225,8 +244,7 @@ class Batched2048:
             raise ValueError("terminal_boards must be a contiguous uint8 [k, n_envs, 16] tensor on the engine's device")
         io = self._io(act, reward, terminated, illegal, highest, terminal_boards)
         fn = self._lib.g2048_rollout_fused if fused else self._lib.g2048_rollout
-        check(fn(self._h, k, C.byref(io), self.n_envs, int(auto_reset), self._stream()))
-        self._fresh = False
+        return _RolloutPlan(self, fn, k, io, int(auto_reset), (act, reward, terminated, illegal, highest, terminal_boards))
 
     def rollout_random(self, k_steps: int):
         """ONE fused launch: ``k_steps`` of the synthetic random policy, boards kept in registers."""
@@ -355,10 +373,19 @@ class Batched2048:
         every finished episode; ``last_*`` describe each board's most recent finished episode."""
         st = Stats()
         check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
-        return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count,
-                    last_score_sum=st.last_score_sum, last_score_max=st.last_score_max, max_exp=st.max_exp,
-                    mean_last_score=(st.last_score_sum / st.last_count) if st.last_count else 0.0,
-                    highest_hist=[int(x) for x in st.highest_hist])
+        return parse_stats(bytes(st))
+
+    def episode_stats_device(self, out=None) -> torch.Tensor:
+        """The same reduction as ``episode_stats`` left ON THE DEVICE: a ``uint8 [sizeof(g2048_stats)]`` tensor
+        holding the C struct, enqueued on the current stream without a host sync (what a multi-GPU job
+        all-gathers once per rollout; decode with ``parse_stats``)."""
+        nbytes = C.sizeof(Stats)
+        if out is None:
+            out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if out.dtype != torch.uint8 or out.numel() != nbytes or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"out must be a contiguous uint8 [{nbytes}] tensor on the engine's device")
+        check(self._lib.g2048_episode_stats_async(self._h, out.data_ptr(), self._stream()))
+        return out
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:
@@ -438,6 +465,19 @@ class Batched2048:
         from .render import render_board
         vals = exp_to_values(self.get_boards()[index])
         return render_board(vals, int(self.get_scores()[index]), mode)
+
+
+def parse_stats(raw) -> dict:
+    """Decode one ``g2048_stats`` struct (bytes / uint8 array / tensor row from ``episode_stats_device``)."""
+    if isinstance(raw, torch.Tensor):
+        raw = raw.cpu().numpy()
+    if not isinstance(raw, (bytes, bytearray)):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8).tobytes()
+    st = Stats.from_buffer_copy(bytes(raw))
+    return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count,
+                last_score_sum=st.last_score_sum, last_score_max=st.last_score_max, max_exp=st.max_exp,
+                mean_last_score=(st.last_score_sum / st.last_count) if st.last_count else 0.0,
+                highest_hist=[int(x) for x in st.highest_hist])
 
 
 def exp_to_values(exps) -> np.ndarray:

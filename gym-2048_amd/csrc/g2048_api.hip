@@ -579,6 +579,19 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     return G2048_OK;
 }
 
+int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, void *stream)
+{
+    static_assert(sizeof(g2048_stats) == sizeof(g2048::StatsOut), "g2048_stats and the kernel's StatsOut must share one layout");
+    if (!e || !device_out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    if (!is_device_ptr(device_out))
+        return fail(G2048_ERR_INVALID, "g2048_episode_stats_async needs a DEVICE buffer (use g2048_episode_stats for a host struct)");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), reinterpret_cast<g2048::StatsOut *>(device_out),
+                                  static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
 int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
 {
     if (!e)

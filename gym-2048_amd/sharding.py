@@ -65,12 +65,25 @@ def allgather_returns(local_returns: torch.Tensor, shard: Shard) -> torch.Tensor
     return torch.cat(parts)
 
 
-def allreduce_summary(episodes: int, score_sum: int, max_score: int, device) -> dict:
-    """Global (episodes, score_sum, max_score) from per-rank episode statistics."""
+def allgather_stats(local_stats: torch.Tensor) -> torch.Tensor:
+    """All-gather the per-rank episodic-return SUMMARY (``Batched2048.episode_stats_device()``: the C struct
+    g2048_stats as ``uint8 [168]``) -> ``uint8 [world, 168]`` on every rank.  A few hundred bytes per rank:
+    one latency-bound RCCL all-gather per rollout (SURVEY 8e's first option)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return dict(episodes=episodes, score_sum=score_sum, max_score=max_score)
-    sums = torch.tensor([episodes, score_sum], dtype=torch.int64, device=device)
-    mx = torch.tensor([max_score], dtype=torch.int64, device=device)
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    return dict(episodes=int(sums[0]), score_sum=int(sums[1]), max_score=int(mx[0]))
+        return local_stats.reshape(1, -1).clone()
+    flat = local_stats.contiguous().reshape(-1)
+    out = torch.empty(dist.get_world_size() * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat)            # flat in, flat out: accepted by RCCL and gloo alike
+    return out.reshape(dist.get_world_size(), flat.numel())
+
+
+def merge_stats(rows) -> dict:
+    """Global summary from the gathered per-rank structs (host side, after the stream has been synchronised)."""
+    from .batched import parse_stats
+    parts = [parse_stats(r) for r in rows]
+    tot = dict(episodes=sum(p["episodes"] for p in parts), illegal_ends=sum(p["illegal_ends"] for p in parts),
+               last_count=sum(p["last_count"] for p in parts), last_score_sum=sum(p["last_score_sum"] for p in parts),
+               last_score_max=max(p["last_score_max"] for p in parts), max_exp=max(p["max_exp"] for p in parts),
+               highest_hist=[sum(col) for col in zip(*(p["highest_hist"] for p in parts))])
+    tot["mean_last_score"] = tot["last_score_sum"] / tot["last_count"] if tot["last_count"] else 0.0
+    return tot

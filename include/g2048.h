@@ -194,6 +194,9 @@ void *g2048_last_records_ptr(const g2048_engine *e);
 
 /* Reduce the episode bookkeeping on the device and copy the result to *out (synchronises `stream`). */
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
+/* The same reduction written to a g2048_stats in DEVICE memory, enqueued on `stream`, no host
+ * synchronisation: the per-rank episodic-return summary a multi-GPU job all-gathers. */
+int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, void *stream);
 
 /* numpy-compatible RNG mode: every board draws from its OWN numpy PCG64 exactly as the reference does
  * through gymnasium's np_random (game2048_env.py:103,168,170: random() < 0.9, then Generator.shuffle of

@@ -17,7 +17,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gym2048_amd.batched import Batched2048
-    from gym2048_amd.sharding import shard_range, allgather_returns, allreduce_summary
+    from gym2048_amd.sharding import shard_range, allgather_returns, allgather_stats, merge_stats
     shard = shard_range(n, rank, world)
     eng = Batched2048(shard.n_local, device=0, seed=seed, board_offset=shard.offset)
     eng.reset()
@@ -25,10 +25,10 @@ def main():
     returns = allgather_returns(eng.last_scores().cpu(), shard)        # gloo: host tensors
     boards = [torch.empty((shard_range(n, r, world).n_local, 16), dtype=torch.uint8) for r in range(world)]
     dist.all_gather(boards, torch.from_numpy(eng.get_boards().reshape(-1, 16)))
-    st = eng.episode_stats()
-    summ = allreduce_summary(st["episodes"], st["last_score_sum"], st["last_score_max"], "cpu")
+    summ = merge_stats(allgather_stats(eng.episode_stats_device().cpu()))    # per-rank summary structs
     if rank == 0:
-        np.savez(out, returns=returns.numpy(), boards=torch.cat(boards).numpy(), episodes=summ["episodes"])
+        np.savez(out, returns=returns.numpy(), boards=torch.cat(boards).numpy(), episodes=summ["episodes"],
+                 last_sum=summ["last_score_sum"], last_max=summ["last_score_max"], hist=np.array(summ["highest_hist"]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -22,7 +22,8 @@ def _free_port():
 
 def _worker(rank, world, port, n_global, steps, seed, out_dir):
     sys.path.insert(0, ROOT)
-    from gym2048_amd.sharding import allgather_returns, allreduce_summary, shard_range
+    from gym2048_amd._lib import Stats
+    from gym2048_amd.sharding import allgather_returns, allgather_stats, merge_stats, shard_range
     from oracle import OracleBatch
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -33,10 +34,20 @@ def _worker(rank, world, port, n_global, steps, seed, out_dir):
             ob.step(None)
         returns = allgather_returns(torch.from_numpy(ob.last_score.copy()), shard)
         boards = allgather_returns(torch.from_numpy(ob.boards.astype(np.int32).sum(axis=1).astype(np.int32)), shard)
-        summ = allreduce_summary(int(ob.ep_count.sum()), int(ob.last_score.sum()), int(ob.last_score.max()), "cpu")
+        # the per-rank summary struct the engine's stats kernel would leave on the device (g2048_stats)
+        had = ob.ep_count > 0
+        st = Stats(episodes=int(ob.ep_count.sum()), illegal_ends=0, last_count=int(had.sum()),
+                   last_score_sum=int(ob.last_score[had].sum()), last_score_max=int(ob.last_score.max()),
+                   max_exp=int(ob.boards.max()))
+        for k, v in enumerate(np.bincount(ob.boards.max(axis=1), minlength=32)):
+            st.highest_hist[k] = int(v)
+        rows = allgather_stats(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+        assert rows.shape == (world, 168)
+        summ = merge_stats(rows)
         if rank == 0:
             np.savez(os.path.join(out_dir, "gathered.npz"), returns=returns.numpy(), boards=boards.numpy(),
-                     episodes=summ["episodes"], max_score=summ["max_score"])
+                     episodes=summ["episodes"], max_score=summ["last_score_max"], last_count=summ["last_count"],
+                     last_sum=summ["last_score_sum"], hist=np.array(summ["highest_hist"]))
     finally:
         dist.destroy_process_group()
 
@@ -54,6 +65,8 @@ def test_sharded_ranks_equal_single_process(tmp_path, n_global, world):
     assert np.array_equal(got["returns"], ref.last_score)                      # global order, bit-exact
     assert np.array_equal(got["boards"], ref.boards.astype(np.int32).sum(axis=1))
     assert int(got["episodes"]) == int(ref.ep_count.sum()) and int(got["max_score"]) == int(ref.last_score.max())
+    assert int(got["last_count"]) == int((ref.ep_count > 0).sum()) and int(got["last_sum"]) == int(ref.last_score.sum())
+    assert np.array_equal(got["hist"], np.bincount(ref.boards.max(axis=1), minlength=32))
 
 
 def test_allgather_single_process_is_identity():

@@ -164,4 +164,8 @@ def test_two_rank_hip_shards_allgather(torch_cuda, tmp_path):
     got = np.load(out)
     assert np.array_equal(got["returns"], whole.get_last_scores())
     assert np.array_equal(got["boards"], whole.get_boards().reshape(n, 16))
-    assert int(got["episodes"]) == whole.episode_stats()["episodes"]
+    st = whole.episode_stats()
+    assert int(got["episodes"]) == st["episodes"] and int(got["last_sum"]) == st["last_score_sum"]
+    assert int(got["last_max"]) == st["last_score_max"] and got["hist"].tolist() == st["highest_hist"]
+    from gym2048_amd.batched import parse_stats
+    assert parse_stats(whole.episode_stats_device()) == st                  # async device struct == sync host struct
