@@ -716,7 +716,7 @@ int g2048_canonicalize(uint8_t *boards, uint8_t *next_boards, uint8_t *actions, 
 }
 
 // ------------------------------------------------------------------------------- collective
-// The path's only exchange step: the all-gather of episodic returns (last_score) once per rollout.
+// The path's only exchange step: the all-gather of episodic returns (scores of last_record) once per rollout.
 // RCCL is bound lazily (dlopen) so that the library loads, and everything else works, on a box without
 // RCCL or without a GPU; a process that never calls g2048_comm_* never touches it.
 } // extern "C"

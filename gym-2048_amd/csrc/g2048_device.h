@@ -14,8 +14,10 @@
 // The slide/merge runs on all four lines at once: the board is re-expressed as four registers
 // A,B,C,D where byte l of A is the FIRST cell of line l (in shift order), B the second, ... so
 // one 32-bit VALU op advances four lines.  For vertical moves A..D are simply the rows (reversed
-// for "down"); for horizontal moves they are the columns, obtained with an 8 x v_perm_b32 byte
-// transpose.  No LDS, no cross-lane traffic: the whole step lives in ~40 VGPRs.
+// for "down"); for horizontal moves they are the columns.  Two formulations of that re-expression:
+// move() -- an 8 x v_perm_b32 byte transpose plus lane-mask selects -- and move_sel(), the one the
+// step kernels use: a two-stage v_perm network whose byte selectors come from a 4-row table, so the
+// direction costs no select instructions at all.  No cross-lane traffic: the step lives in ~42 VGPRs.
 #pragma once
 
 #include <stdint.h>

@@ -104,7 +104,7 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
 int g2048_destroy(g2048_engine *e);
 
 /* gym.Env.reset(seed=...) seeding half (game2048_env.py:103): restart the spawn stream (t = 0) and
- * clear the episode statistics (last_score, episode accumulators) with a kernel enqueued on `stream`
+ * clear the episode statistics (terminal records, episode counters) with a kernel enqueued on `stream`
  * (ordered against steps already enqueued there; no host synchronisation). */
 int g2048_seed(g2048_engine *e, uint64_t seed, void *stream);
 int g2048_get_clock(const g2048_engine *e, uint64_t *t);
@@ -251,7 +251,7 @@ int g2048_comm_create(int world, int rank, const uint8_t id[G2048_COMM_ID_BYTES]
 int g2048_comm_destroy(g2048_comm *c);
 int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, void *stream);
 /* One process driving several GPUs: engines[r] on distinct devices with equal board counts; a
- * communicator set is built with ncclCommInitAll, every engine's last_score is all-gathered into
+ * communicator set is built with ncclCommInitAll, every engine's last returns are all-gathered into
  * outs[r][n_engines * n] (device memory on engine r's device) on streams[r] (NULL = null streams), the
  * streams are synchronised and the communicators destroyed. */
 int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, int32_t *const *outs,
