@@ -21,10 +21,23 @@ def test_constants_match_the_roofline_model():
 
 def test_committed_traffic_profile_is_consistent():
     t = bench.load_traffic()
-    assert t and t["kernel"] == "step_kernel"
+    assert t and t["kernel"] == "step_kernel" and t["profile"] and len(t["csrc_sha16"]) == 16
     algorithmic = bench.ALGO_BYTES_PER_STEP * (1 << 20)
-    assert algorithmic < t["bytes_per_launch"] < 1.5 * algorithmic
+    assert algorithmic < t["bytes_per_launch"] < 1.15 * algorithmic          # round 2: x1.08 (round 1: x1.28)
     assert abs(t["crosscheck_dram_32b_bytes_per_launch"] - t["bytes_per_launch"]) < 0.02 * t["bytes_per_launch"]
+
+
+def test_traffic_is_reported_only_for_the_profiled_sources(monkeypatch):
+    """roofline.traffic comes from a committed profile: it is printed for the profiled batch size while the
+    kernel sources hash to what was profiled, and is null otherwise (a stale profile never goes unnoticed)."""
+    t = bench.load_traffic()
+    monkeypatch.setattr(bench, "csrc_hash", lambda: t["csrc_sha16"])
+    val, prov = bench.traffic_for_current_sources(1 << 20)
+    assert val == t["bytes_per_launch"] and prov["profile"] == t["profile"]
+    assert bench.traffic_for_current_sources(1 << 16)[0] is None
+    monkeypatch.setattr(bench, "csrc_hash", lambda: "0" * 16)
+    val, prov = bench.traffic_for_current_sources(1 << 20)
+    assert val is None and prov["profiled_csrc"] == t["csrc_sha16"] and prov["current_csrc"] == "0" * 16
 
 
 def test_committed_bench_lines_carry_the_contract_fields():
