@@ -42,6 +42,8 @@ static inline uint32_t g2048_popc(uint32_t x) { return (uint32_t)__builtin_popco
 static inline uint32_t g2048_opaque(uint32_t x) { return x; }
 static inline uint32_t g2048_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
 static inline bool g2048_any(bool x) { return x; }
+static inline uint32_t g2048_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+template <int K> static inline uint32_t g2048_pow2_byte(uint32_t x, uint32_t) { return 1u << ((x >> (8 * K)) & 31u); }
 #else
 #include <hip/hip_runtime.h>
 #define G2048_DEV __device__ __forceinline__
@@ -58,6 +60,23 @@ G2048_DEV uint32_t g2048_opaque(uint32_t x)
 }
 // (m & a) | (~m & b) as ONE v_bitop3_b32 (2 issue cycles; v_bfi_b32 / v_cndmask_e64 take 4).
 G2048_DEV uint32_t g2048_bfi(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
+// a ^ b ^ c as ONE v_bitop3_b32 (the compiler emits two v_xor_b32 for the Philox rounds otherwise).
+G2048_DEV uint32_t g2048_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+// 1 << (byte K of x, low five bits) as ONE instruction: SDWA selects the byte as the shift operand of
+// v_lshlrev_b32 (the compiler emits a v_lshrrev + v_lshl_add pair per byte otherwise).  `one` = a VGPR holding 1.
+template <int K> G2048_DEV uint32_t g2048_pow2_byte(uint32_t x, uint32_t one)
+{
+    uint32_t r;
+    if constexpr (K == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(one));
+    else if constexpr (K == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(one));
+    else if constexpr (K == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(one));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(one));
+    return r;
+}
 // true when the predicate holds in any active lane of the wavefront (wave-uniform).
 G2048_DEV bool g2048_any(bool x) { return __ballot(x) != 0ull; }
 #endif
@@ -86,8 +105,8 @@ G2048_DEV Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     for (int round = 0; round < 10; ++round) {
         const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
         const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = g2048_xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = g2048_xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -171,10 +190,10 @@ G2048_DEV uint32_t shift4(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
     //    are set to 31, whose 2^31 terms can only disturb bit 31, which the final mask drops.
     const uint32_t m1 = bfi(mab, a1, bfi(mbc, b1, 0x1f1f1f1fu)); // first merge of each line
     const uint32_t m2 = bfi(mcd, c1, 0x1f1f1f1fu);               // second merge of each line
-    uint32_t score = (1u << (m1 & 31u)) + (1u << (m2 & 31u));
-#pragma unroll
-    for (int l = 1; l < 4; ++l)
-        score += (1u << ((m1 >> (8 * l)) & 31u)) + (1u << ((m2 >> (8 * l)) & 31u));
+    const uint32_t one = g2048_opaque(1u);
+    const uint32_t score = (g2048_pow2_byte<0>(m1, one) + g2048_pow2_byte<1>(m1, one) + g2048_pow2_byte<2>(m1, one)) +
+                           (g2048_pow2_byte<3>(m1, one) + g2048_pow2_byte<0>(m2, one) + g2048_pow2_byte<1>(m2, one)) +
+                           (g2048_pow2_byte<2>(m2, one) + g2048_pow2_byte<3>(m2, one));
     return score & 0x7fffffffu;
 }
 

@@ -65,7 +65,7 @@ def torch_cuda():
 
 
 TRAJECTORIES = ["traj_random_seed42", "traj_random_offset", "traj_greedy_irw", "traj_greedy_max256",
-                "traj_noautoreset"]
+                "traj_noautoreset", "traj_corner_deep"]
 
 
 def replay_trajectory(make_batch, d, check_terminal=True):

@@ -229,7 +229,7 @@ def greedy_action(legal, random_a, t):
 
 def gen_trajectories(ref, name, seed, n_boards, n_steps, policy, board_offset=0,
                      illegal_move_reward=None, max_tile=None, auto_reset=True):
-    """policy: 'random' (the synthetic benchmark policy) or 'greedy' (see greedy_action)."""
+    """policy: 'random' (the synthetic benchmark policy), 'greedy' (see greedy_action) or 'corner'."""
     shape = (n_boards, n_steps)
     out = dict(actions=np.zeros(shape, np.uint8), reward=np.zeros(shape, np.float32),
                terminated=np.zeros(shape, np.uint8), illegal=np.zeros(shape, np.uint8),
@@ -244,6 +244,9 @@ def gen_trajectories(ref, name, seed, n_boards, n_steps, policy, board_offset=0,
             a = random_action(seed, t, board_offset + b)
             if policy == "greedy":
                 a = greedy_action(drv.legal_actions(), a, t)
+            elif policy == "corner":      # always legal: first legal of left, down, right, up -> games end on full boards
+                legal = drv.legal_actions()
+                a = next((d for d in (3, 2, 1, 0) if d in legal), a)
             rec = drv.step(a, auto_reset)
             out["actions"][b, s] = a
             out["reward"][b, s] = rec["reward"]
@@ -573,6 +576,7 @@ def main():
         print("\n".join(report))
         return
     if args.only_round2:
+        save("traj_corner_deep.npz", gen_trajectories(ref, "corner_deep", 31, 48, 1024, "corner"))
         save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
         save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
         print("\n".join(report))
@@ -597,6 +601,7 @@ def main():
     save("traj_greedy_max256.npz", gen_trajectories(ref, "greedy_max256", 2024, 16, 768, "greedy",
                                                     max_tile=256))
     save("traj_noautoreset.npz", gen_trajectories(ref, "noautoreset", 5, 16, 96, "random", auto_reset=False))
+    save("traj_corner_deep.npz", gen_trajectories(ref, "corner_deep", 31, 48, 1024, "corner"))
     save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
     save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
     validate(ref, args.validate_steps, report)
