@@ -420,8 +420,15 @@ class Batched2048:
                     terminal_boards=packed[off + 3 * n:off + 19 * n].reshape(n, 4, 4).copy(),
                     boards=packed[off + 19 * n:off + 35 * n].reshape(n, 4, 4).copy())
 
-    def onehot_numpy(self) -> np.ndarray:
-        return self.observe_onehot(torch.uint8).cpu().numpy()
+    def onehot_numpy(self, dtype=np.uint8) -> np.ndarray:
+        """Host copy of the one-hot observation in ``dtype``.  The kernel writes uint8; a wider integer type is
+        produced by widening ON THE DEVICE and copying once (a host-side ``astype`` of 2 KiB per env was the
+        slowest part of the VecEnv adapter)."""
+        obs = self.observe_onehot(torch.uint8)
+        dtype = np.dtype(dtype)
+        if dtype != np.uint8:
+            obs = obs.to(getattr(torch, dtype.name))
+        return obs.cpu().numpy()
 
     def move(self, actions, trial: bool = False):
         """game2048_env.py:194-241 alone: returns device ``(score int32[n], legal uint8[n])``."""

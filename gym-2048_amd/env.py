@@ -88,6 +88,8 @@ class Game2048Env(_env_base()):
             from .batched import Batched2048
             engine = Batched2048(1, device=device, seed=int.from_bytes(os.urandom(7), "little"), rng=rng)
         self._eng = engine
+        self._scratch = None    # a one-board engine for shift(), created on first use
+        self._scratch_factory = getattr(engine, "scratch_factory", None)
         self._slot = 0          # next spawn slot of the current transaction
         self.set_illegal_move_reward(0.0)
         self.set_max_tile(None)
@@ -151,7 +153,7 @@ class Game2048Env(_env_base()):
 
     # ------------------------------------------------------------------ board access
     def _obs(self):
-        return self._eng.onehot_numpy()[0].astype(int)
+        return self._eng.onehot_numpy(np.int64)[0]
 
     @property
     def Matrix(self):
@@ -203,16 +205,15 @@ class Game2048Env(_env_base()):
         return int(score[0])
 
     def shift(self, row):
-        """game2048_env.py:243-260 (runs as a left move of a scratch board holding ``row``)."""
-        saved = self._eng.get_boards()
-        try:
-            board = np.zeros((1, 4, 4), np.uint8)
-            board[0, 0] = _values_to_exp(row)
-            self._eng.set_boards(board)
-            score, _ = self._eng.move_numpy(np.array([3]), trial=False)
-            out = _exp_to_values(self._eng.get_boards()[0, 0])
-        finally:
-            self._eng.set_boards(saved)
+        """game2048_env.py:243-260 (runs as a left move of a SCRATCH engine's board holding ``row``; the env's
+        own board is not touched)."""
+        if self._scratch is None:
+            self._scratch = type(self._eng)(1) if self._scratch_factory is None else self._scratch_factory()
+        board = np.zeros((1, 4, 4), np.uint8)
+        board[0, 0] = _values_to_exp(row)
+        self._scratch.set_boards(board)
+        score, _ = self._scratch.move_numpy(np.array([3]), trial=False)
+        out = _exp_to_values(self._scratch.get_boards()[0, 0])
         return [int(v) for v in out], int(score[0])
 
     def isend(self):

@@ -155,7 +155,7 @@ class Vec2048(_vec_env_base()):
         return list(indices)
 
     def _obs(self):
-        return self.engine.onehot_numpy().astype(self.obs_dtype, copy=False)
+        return self.engine.onehot_numpy(self.obs_dtype)
 
 
 def _onehot_host(boards_exp: np.ndarray, dtype) -> np.ndarray:

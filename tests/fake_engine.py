@@ -52,8 +52,8 @@ class OracleEngine:
     def get_scores(self):
         return self.ob.score.copy()
 
-    def onehot_numpy(self):
-        return self.ob.onehot()
+    def onehot_numpy(self, dtype=np.uint8):
+        return self.ob.onehot().astype(dtype, copy=False)
 
     def _values(self, i):
         return I64x16(*[0 if e == 0 else 1 << int(e) for e in self.ob.boards[i]])
