@@ -169,3 +169,39 @@ def test_two_rank_hip_shards_allgather(torch_cuda, tmp_path):
     assert int(got["last_max"]) == st["last_score_max"] and got["hist"].tolist() == st["highest_hist"]
     from gym2048_amd.batched import parse_stats
     assert parse_stats(whole.episode_stats_device()) == st                  # async device struct == sync host struct
+
+
+def test_more_than_4_gib_of_records(torch_cuda):
+    """2^28 + 4133 boards = 4 GiB + of records in ONE engine (the layout is sized for 288 GB): byte offsets of
+    the records, the terminal records and the [K][N] float rewards exceed 32 bits.  Sharding invariance makes
+    the check cheap: windows at the start, across the 4 GiB line and at the end must play exactly the games
+    of small engines created with the same global board offsets, which in turn are checked against the oracle."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, k, win = (1 << 28) + 4096 + 37, 5, 12, 2048
+    big = Batched2048(n, seed=seed)
+    big.reset()
+    offsets = [0, (1 << 28) - win // 2, n - win]
+    small = [Batched2048(win, seed=seed, board_offset=o) for o in offsets]
+    oracles = [OracleBatch(win, seed, o, threads=0) for o in offsets]
+    for e in small + oracles:
+        e.reset()
+    reward = torch.zeros((2, n), dtype=torch.float32, device=big.device)      # row 1 starts beyond 1 GiB, ends beyond 2 GiB
+    for s in range(k):
+        big.rollout(1, reward=reward[1:2])
+        for e in small + oracles:
+            e.step(None)
+        recs = big.records()
+        for o, e, ora in zip(offsets, small, oracles):
+            assert torch.equal(recs[o:o + win], e.records()), (s, o)
+            assert np.array_equal(reward[1, o:o + win].cpu().numpy(), ora.reward), (s, o)
+            assert np.array_equal((e.records().cpu().numpy() & 0x1F), ora.boards), (s, o)
+    assert big.clock == k
+    last = big.last_records()
+    for o, e, ora in zip(offsets, small, oracles):
+        assert torch.equal(last[o:o + win], e.last_records())
+        assert np.array_equal(e.get_last_scores(), ora.last_score)
+    st = big.episode_stats()
+    assert st["episodes"] > n // 2 and sum(st["highest_hist"]) == n
+    big.close()
