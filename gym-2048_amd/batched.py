@@ -405,20 +405,52 @@ class Batched2048:
 
     # ------------------------------------------------------------------ numpy facade (used by the
     # single-env and VecEnv adapters; tests replace this object by an oracle-backed fake)
+    def _host_staging(self):
+        """Buffers of the host-array path, created on first use: a pinned int64 action buffer and ONE packed
+        output buffer on the device (reward | terminated | illegal | highest | terminal boards | boards, each
+        part 16-byte aligned) with its pinned host twin -- a host step is one upload, two kernels, one download."""
+        if getattr(self, "_stage", None) is None:
+            n = self.n_envs
+            up = lambda x: (x + 15) & ~15  # noqa: E731
+            off, sizes = {}, (("reward", 4 * n), ("terminated", n), ("illegal", n), ("highest", n),
+                              ("terminal_boards", 16 * n), ("boards", 16 * n))
+            pos = 0
+            for name, size in sizes:
+                off[name] = (pos, size)
+                pos = up(pos + size)
+            dev = torch.zeros(pos, dtype=torch.uint8, device=self.device)
+            view = {k: dev[o:o + sz] for k, (o, sz) in off.items()}
+            self._stage = dict(
+                off=off, dev=dev, host=torch.zeros(pos, dtype=torch.uint8).pin_memory(),
+                act_host=torch.zeros(n, dtype=torch.int64).pin_memory(),
+                act_dev=torch.zeros(n, dtype=torch.int64, device=self.device),
+                reward=view["reward"].view(torch.float32), terminated=view["terminated"], illegal=view["illegal"],
+                highest=view["highest"], terminal_boards=view["terminal_boards"].view(n, 16), boards=view["boards"])
+        return self._stage
+
     def step_numpy(self, actions, auto_reset: bool = True) -> dict:
         """Step with host actions and bring every per-step output back in ONE device-to-host copy
-        (reward, terminated, illegal, highest, terminal boards, boards after the step)."""
-        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int64))
-        self.step(a, auto_reset=auto_reset, want_info=True)
+        (reward, terminated, illegal, highest, terminal boards, boards after the step) through pinned memory."""
+        st = self._host_staging()
         n = self.n_envs
-        packed = torch.cat([self.reward.view(torch.uint8), self.terminated, self.illegal, self.highest,
-                            self.terminal_boards.reshape(-1), self.boards().reshape(-1)]).cpu().numpy()
-        off = 4 * n
-        return dict(reward=packed[:off].view(np.float32).copy(),
-                    terminated=packed[off:off + n].astype(bool), illegal=packed[off + n:off + 2 * n].astype(bool),
-                    highest=packed[off + 2 * n:off + 3 * n].copy(),
-                    terminal_boards=packed[off + 3 * n:off + 19 * n].reshape(n, 4, 4).copy(),
-                    boards=packed[off + 19 * n:off + 35 * n].reshape(n, 4, 4).copy())
+        st["act_host"].numpy()[:] = np.asarray(actions).reshape(n)
+        st["act_dev"].copy_(st["act_host"], non_blocking=True)
+        io = self._io(st["act_dev"], st["reward"], st["terminated"], st["illegal"], st["highest"], st["terminal_boards"])
+        check(self._lib.g2048_step(self._h, C.byref(io), int(auto_reset), self._stream()))
+        self._fresh = False
+        check(self._lib.g2048_get_boards(self._h, st["boards"].data_ptr(), self._stream()))
+        st["host"].copy_(st["dev"], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        raw = st["host"].numpy()
+        part = lambda k: raw[st["off"][k][0]: st["off"][k][0] + st["off"][k][1]]  # noqa: E731
+        # keep the engine's public per-step views coherent with what was just computed
+        self.reward, self.terminated, self.illegal, self.highest = st["reward"], st["terminated"], st["illegal"], st["highest"]
+        self.terminal_boards = st["terminal_boards"]
+        return dict(reward=part("reward").view(np.float32).copy(),
+                    terminated=part("terminated").astype(bool), illegal=part("illegal").astype(bool),
+                    highest=part("highest").copy(),
+                    terminal_boards=part("terminal_boards").reshape(n, 4, 4).copy(),
+                    boards=part("boards").reshape(n, 4, 4).copy())
 
     def onehot_numpy(self, dtype=np.uint8) -> np.ndarray:
         """Host copy of the one-hot observation in ``dtype``.  The kernel writes uint8; a wider integer type is
