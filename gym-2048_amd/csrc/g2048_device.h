@@ -231,7 +231,8 @@ G2048_DEV uint32_t count_empty(const Board &bd)
 // game2048_env.py:166-176 with the injected spawn word w: value 2 (exp 1) if (w & 0xffff) <= 58982
 // else 4 (exp 2); position = k-th empty cell in row-major order, k = (w * n_empty) >> 32.
 // `enable` (all-ones / 0) gates the write.  Returns the number of empty cells BEFORE the spawn.
-G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable = 0xffffffffu)
+// `is2` = "the new tile is a 2", i.e. (w & 0xffff) <= 58982 (passed in where the caller needs it as well).
+G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable, bool is2)
 {
     const uint32_t z0 = z80(bd.r[0]), z1 = z80(bd.r[1]), z2 = z80(bd.r[2]), z3 = z80(bd.r[3]);
     const uint32_t c0 = g2048_popc(z0), c1 = c0 + g2048_popc(z1), c2 = c1 + g2048_popc(z2),
@@ -248,12 +249,17 @@ G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable = 0xffffffffu
     const uint32_t prefix = (zs >> 7) * 0x01010101u;
     const uint32_t hit = ~((prefix ^ want) + kLow7) & zs;              // 0x80 at the chosen cell only
     // exponent 1 -> 0x01 at that byte (hit >> 7), exponent 2 -> 0x02 (hit >> 6)
-    const uint32_t tile = (hit >> (((w & 0xffffu) <= 58982u) ? 7u : 6u)) & enable;
+    const uint32_t tile = (hit >> (is2 ? 7u : 6u)) & enable;
     bd.r[0] |= tile & ~g0;
     bd.r[1] |= tile & g0 & ~g1;
     bd.r[2] |= tile & g1 & ~g2;
     bd.r[3] |= tile & g2;
     return n;
+}
+
+G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable = 0xffffffffu)
+{
+    return add_tile(bd, w, enable, (w & 0xffffu) <= 58982u);
 }
 
 // game2048_env.py:102-111: empty board + two spawns from words w1, w2.
@@ -487,9 +493,11 @@ G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint3
     StepOut o;
     Board cells = record_cells(rec);
     o.legal = move_sel(cells, tb.move_sel(action), o.gain);        // :85 (illegal: board unchanged, gain 0)
+    const uint32_t lm = lanemask(o.legal);
+    const bool is2 = (w.w[0] & 0xffffu) <= 58982u;                 // :168 the spawn's value
     // :88 add_tile needs an empty cell; a board that changed always has one (a full board can only
     // change by merging).  After an illegal move nothing is spawned (:91-95).
-    const uint32_t n_empty = add_tile(cells, w.w[0], lanemask(o.legal));
+    const uint32_t n_empty = add_tile(cells, w.w[0], lm, is2);
     // :89 isend(): the board is full after the spawn exactly when it had one empty cell before it
     bool end = false;
     if (n_empty == 1u)                                             // :270-271
@@ -498,12 +506,12 @@ G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint3
         end = true;
     o.terminated = o.legal ? end : true;                           // :89, :94
     // a spawned 4 raises the potential without scoring: deficit += 4 (bit 2 of d = bit 7 of byte 8)
-    const uint32_t inc = (o.legal && (w.w[0] & 0xffffu) > 58982u) ? 0x80u : 0u;
+    const uint32_t inc = (o.legal && !is2) ? 0x80u : 0u;
     record_update(rec, cells, inc);
     o.terminal = rec;
     const bool do_reset = o.terminated && auto_reset;
     if (g2048_any(do_reset)) {                                     // wave-uniform: skipped when nobody finished
-        const uint32_t lm = lanemask(o.legal), rm = lanemask(do_reset);
+        const uint32_t rm = lanemask(do_reset);
         const Board fb = fresh_record_lut(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]), tb); // :104-109
         rec.r[0] = bfi(rm, fb.r[0], rec.r[0]);
         rec.r[1] = bfi(rm, fb.r[1], rec.r[1]);

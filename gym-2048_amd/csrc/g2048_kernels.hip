@@ -51,21 +51,33 @@ __device__ __forceinline__ void store_board(uint4 *boards, uint32_t i, const Boa
     boards[i] = make_uint4(b.r[0], b.r[1], b.r[2], b.r[3]);
 }
 
-// Per-WAVEFRONT lookup tables in LDS (384 B): the per-action selector rows of move_sel and the 16
-// one-tile boards of fresh_record_lut (g2048_device.h).  Each wavefront stages its own copy -- lanes
-// 0..31 fetch one selector word each (global load, L2-resident), every lane computes one word of the
-// one-tile table -- and only reads what it wrote itself, so no workgroup barrier is involved.
-__device__ const uint32_t kMoveLut[32] = {G2048_MOVE_LUT_WORDS};
-
+// Per-WAVEFRONT lookup tables in LDS (512 B): the per-action selector rows of move_sel and the 16
+// one-tile boards of fresh_record_lut (g2048_device.h).  Each wavefront stages its own copy -- every lane
+// fetches ONE 8-byte piece of the 512-byte image below (global load, L2-resident) and writes it to LDS at
+// byte offset threadIdx.x * 8 -- and only reads what it wrote itself, so no workgroup barrier is involved.
 struct WaveTables {
     uint32_t move[32]; // 4 actions x 8 words (6 used)
-    uint32_t cell[64]; // 16 cells x 4 words
+    uint32_t cell[64]; // 16 cells x 4 words: entry p = the board whose only tile is a 2 (exponent 1) in cell p
+    uint32_t pad[32];  // 64 lanes x 8 bytes
 };
 
+// word j of entry p of the one-tile table (= onehot_cell_word(p, j) of g2048_device.h, as a constant expression)
+#define G2048_CELL_ENTRY(p) ((p) / 4 == 0 ? 1u << (8 * ((p) % 4)) : 0u), ((p) / 4 == 1 ? 1u << (8 * ((p) % 4)) : 0u), \
+                            ((p) / 4 == 2 ? 1u << (8 * ((p) % 4)) : 0u), ((p) / 4 == 3 ? 1u << (8 * ((p) % 4)) : 0u)
+__device__ const uint32_t kWaveTablesImage[128] __attribute__((aligned(16))) = {
+    G2048_MOVE_LUT_WORDS,
+    G2048_CELL_ENTRY(0), G2048_CELL_ENTRY(1), G2048_CELL_ENTRY(2), G2048_CELL_ENTRY(3),
+    G2048_CELL_ENTRY(4), G2048_CELL_ENTRY(5), G2048_CELL_ENTRY(6), G2048_CELL_ENTRY(7),
+    G2048_CELL_ENTRY(8), G2048_CELL_ENTRY(9), G2048_CELL_ENTRY(10), G2048_CELL_ENTRY(11),
+    G2048_CELL_ENTRY(12), G2048_CELL_ENTRY(13), G2048_CELL_ENTRY(14), G2048_CELL_ENTRY(15),
+    /* pad[32] = 0 */
+};
+#undef G2048_CELL_ENTRY
+
 // `x`, but not before `dep` has been computed (pins the s_waitcnt of a load below independent work).
-__device__ __forceinline__ uint32_t use_after(uint32_t x, uint32_t dep)
+__device__ __forceinline__ uint2 use_after(uint2 x, uint32_t dep)
 {
-    asm volatile("" : "+v"(x) : "v"(dep));
+    asm volatile("" : "+v"(x.x), "+v"(x.y) : "v"(dep));
     return x;
 }
 
@@ -85,20 +97,20 @@ struct LdsTables {
 };
 
 // Two halves so that the global load is issued early and waited for late (after the Philox block).
-__device__ __forceinline__ uint32_t load_move_lut_word() { return kMoveLut[threadIdx.x & 31u]; }
-
-__device__ __forceinline__ LdsTables stage_tables(WaveTables *all, uint32_t lut_word)
+__device__ __forceinline__ uint2 load_tables_piece()
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    WaveTables *t = all + (threadIdx.x >> 6);
-    if (lane < 32u)
-        t->move[lane] = lut_word;
-    t->cell[lane] = onehot_cell_word(lane >> 2, lane & 3u);
+    return reinterpret_cast<const uint2 *>(kWaveTablesImage)[threadIdx.x & 63u];
+}
+
+__device__ __forceinline__ LdsTables stage_tables(WaveTables *all, uint2 piece)
+{
+    // wave w's copy starts at w * 512 bytes and lane l writes bytes [8l, 8l + 8): together threadIdx.x * 8
+    reinterpret_cast<uint2 *>(all)[threadIdx.x] = piece;
     // same-wave LDS writes are visible to the wave's later reads in program order; the fence only
     // keeps the compiler from moving those reads up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return LdsTables{t};
+    return LdsTables{all + (threadIdx.x >> 6)};
 }
 
 template <int ACT>
@@ -167,22 +179,23 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 // the loads, so it runs while they are in flight) -> step_record (move through the lane's selector row,
 // spawn, done detection, deficit update, auto-reset through the one-tile table) -> store record, reward,
 // terminated.  No barrier, no cross-wave traffic.
-template <int ACT>
+// FULL: the batch is a whole number of blocks (n % 256 == 0), no lane is past the end.
+template <int ACT, bool FULL>
 __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
 {
     __shared__ WaveTables s_tables[kBlock / 64];
     // Lanes past the end stay active (whole wavefronts for the ballots): they recompute board n-1
     // and write nothing.
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i_raw < p.n;
+    const bool valid = FULL || i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
     Board rec = load_board_nt(p.st.boards, i);
-    const uint32_t lut_word = load_move_lut_word();
+    const uint2 tables_piece = load_tables_piece();
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
 
     const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
     const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
-    const LdsTables tb = stage_tables(s_tables, use_after(lut_word, w.w[0]));
+    const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
 
     const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
 
@@ -211,7 +224,7 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
     Board rec = load_board(p.st.boards, i);
-    const LdsTables tb = stage_tables(s_tables, load_move_lut_word());
+    const LdsTables tb = stage_tables(s_tables, load_tables_piece());
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
     uint32_t episodes = 0, illegal_ends = 0;
@@ -238,7 +251,7 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
     Board rec = load_board_nt(p.st.boards, i);
-    const LdsTables tb = stage_tables(s_tables, load_move_lut_word());
+    const LdsTables tb = stage_tables(s_tables, load_tables_piece());
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
     uint32_t episodes = 0, illegal_ends = 0;
@@ -734,11 +747,16 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     if (a.n == 0)
         return hipSuccess;
     const dim3 g = grid_for(a.n), b(kBlock);
-    switch (action_dtype) {
-    case 0: hipLaunchKernelGGL(step_kernel<0>, g, b, 0, s, a); break;
-    case 1: hipLaunchKernelGGL(step_kernel<1>, g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(step_kernel<2>, g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(step_kernel<3>, g, b, 0, s, a); break;
+    const bool full = a.n % kBlock == 0;
+    switch (action_dtype * 2 + (full ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((step_kernel<0, false>), g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((step_kernel<0, true>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((step_kernel<1, false>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((step_kernel<1, true>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((step_kernel<2, false>), g, b, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((step_kernel<2, true>), g, b, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((step_kernel<3, false>), g, b, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((step_kernel<3, true>), g, b, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -24,7 +25,12 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
        X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
-       X_PREFETCH_BLOCKS = 65536 };
+       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072 };
+
+template <class T> __device__ __forceinline__ T *off32(T *base, uint32_t i)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<std::remove_const_t<T> *>(base)) + i * static_cast<uint32_t>(sizeof(T)));
+}
 
 template <int X>
 __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
@@ -51,8 +57,13 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
     const uint32_t lane = threadIdx.x & 63u;
-    Board rec = load_board_nt(p.st.boards, i);
-    const uint32_t lut_word = load_move_lut_word();
+    Board rec;
+    if (X & X_OFF32) {
+        const u32x4 v = __builtin_nontemporal_load(off32(reinterpret_cast<const u32x4 *>(p.st.boards), i));
+        rec = Board{{v.x, v.y, v.z, v.w}};
+    } else
+        rec = load_board_nt(p.st.boards, i);
+    const uint2 tables_piece = load_tables_piece();
     // lanes 0,1 of the block touch the NEXT step's 256 action bytes of this block (one dword per 128-byte
     // line), issued with the board load: the line is in the Infinity Cache when the next launch wants it
     uint32_t touched = 0;
@@ -78,9 +89,14 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
         action = (d >> (8u * (lane & 3u))) & 3u;
     } else
         action = load_action<1>(p.actions, i, 0u);
-    const LdsTables tb = stage_tables(s_tables, use_after(lut_word, w.w[0]));
+    const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
     const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
-    if (valid) {
+    if (valid && (X & X_OFF32)) {
+        const u32x4 v = {rec.r[0], rec.r[1], rec.r[2], rec.r[3]};
+        __builtin_nontemporal_store(v, off32(reinterpret_cast<u32x4 *>(p.st.boards), i));
+        __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, off32(p.reward, i));
+        __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), off32(p.terminated, i));
+    } else if (valid) {
         store_board_nt(p.st.boards, i, rec);
         if (!(X & X_NO_REWARD)) {
             if (X & X_REWARD_U16)
@@ -131,6 +147,15 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
                 for (uint32_t q = 0; q < STRIDE; ++q)
                     dst[q] = v;
             }
+            episodes += (uint32_t)__popcll(done);
+            illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
+        }
+    } else if (X & X_OFF32) {
+        const bool fin = o.terminated && valid;
+        const unsigned long long done = __ballot(fin);
+        if (done) {
+            if (fin)
+                *off32(p.st.last_record, i) = make_uint4(o.terminal.r[0], o.terminal.r[1], o.terminal.r[2], o.terminal.r[3]);
             episodes += (uint32_t)__popcll(done);
             illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
         }
@@ -250,6 +275,7 @@ int main(int argc, char **argv)
     vs.push_back({"x   ring + scalar counters + action touch", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_RING | X_PREFETCH>(a2); }});
     vs.push_back({"x   scalar counters + action touch", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD | X_PREFETCH>(a2); }});
     vs.push_back({"x   scalar counters (= product now)", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD>(a2); }});
+    vs.push_back({"x   32-bit byte offsets (SGPR base + VGPR offset addressing), n <= 2^28 only", [&](uint32_t j) { io2(j); launch_x<X_OFF32>(a2); }});
     vs.push_back({"x   scalar counters + prefetch blocks at the head of the grid", [&](uint32_t j) { io2(j); launch_x<X_COUNT_SLOAD | X_PREFETCH_BLOCKS>(a2); }});
 
     hipEvent_t e0, e1;
