@@ -77,8 +77,9 @@ template <int K> G2048_DEV uint32_t g2048_pow2_byte(uint32_t x, uint32_t one)
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(one));
     return r;
 }
-// true when the predicate holds in any active lane of the wavefront (wave-uniform).
-G2048_DEV bool g2048_any(bool x) { return __ballot(x) != 0ull; }
+// true when the predicate holds in any active lane of the wavefront (wave-uniform).  The builtin takes the
+// predicate as a lane mask; HIP's __ballot(int) would first materialise it as 0/1 in a VGPR and compare again.
+G2048_DEV bool g2048_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 #endif
 
 namespace g2048 {
@@ -250,10 +251,12 @@ G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable, bool is2)
     const uint32_t hit = ~((prefix ^ want) + kLow7) & zs;              // 0x80 at the chosen cell only
     // exponent 1 -> 0x01 at that byte (hit >> 7), exponent 2 -> 0x02 (hit >> 6)
     const uint32_t tile = (hit >> (is2 ? 7u : 6u)) & enable;
-    bd.r[0] |= tile & ~g0;
-    bd.r[1] |= tile & g0 & ~g1;
-    bd.r[2] |= tile & g1 & ~g2;
-    bd.r[3] |= tile & g2;
+    // one-hot row masks from the nested g's (kept as values: one v_bitop3 per row instead of compare + select)
+    const uint32_t h0 = g2048_opaque(g0), h1 = g2048_opaque(g1), h2 = g2048_opaque(g2);
+    bd.r[0] |= tile & ~h0;
+    bd.r[1] |= tile & (h0 ^ h1);
+    bd.r[2] |= tile & (h1 ^ h2);
+    bd.r[3] |= tile & h2;
     return n;
 }
 
@@ -509,15 +512,10 @@ G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint3
     const uint32_t inc = (o.legal && !is2) ? 0x80u : 0u;
     record_update(rec, cells, inc);
     o.terminal = rec;
-    const bool do_reset = o.terminated && auto_reset;
-    if (g2048_any(do_reset)) {                                     // wave-uniform: skipped when nobody finished
-        const uint32_t rm = lanemask(do_reset);
-        const Board fb = fresh_record_lut(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]), tb); // :104-109
-        rec.r[0] = bfi(rm, fb.r[0], rec.r[0]);
-        rec.r[1] = bfi(rm, fb.r[1], rec.r[1]);
-        rec.r[2] = bfi(rm, fb.r[2], rec.r[2]);
-        rec.r[3] = bfi(rm, fb.r[3], rec.r[3]);
-    }
+    // the caller's `if terminated: env.reset()` -- a plain divergent branch: only the lanes that reset execute
+    // it (exec-masked writes straight into the record, no selects), and the wavefront skips it when none does
+    if (o.terminated && auto_reset)
+        rec = fresh_record_lut(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]), tb); // :104-109
     return o;
 }
 

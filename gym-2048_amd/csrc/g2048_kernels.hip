@@ -133,7 +133,7 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
 __device__ __forceinline__ void record_episode_ends(const StepArgs &p, uint32_t i, bool fin, bool illegal, const Board &terminal,
                                                     uint32_t &episodes, uint32_t &illegal_ends)
 {
-    const unsigned long long done = __ballot(fin);
+    const unsigned long long done = __builtin_amdgcn_ballot_w64(fin);
     if (done == 0ull)
         return;
     if (fin) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void record_episode_ends(const StepArgs &p, uint32_t 
             store_board(p.terminal_boards, i, record_cells(terminal));
     }
     episodes += static_cast<uint32_t>(__popcll(done));
-    illegal_ends += static_cast<uint32_t>(__popcll(__ballot(fin && illegal)));
+    illegal_ends += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(fin && illegal)));
 }
 
 // The wave's counter pair is private to it (one wavefront per pair per launch, launches are
