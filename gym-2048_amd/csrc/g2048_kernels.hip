@@ -527,6 +527,13 @@ __global__ void __launch_bounds__(kBlock) fill_actions_kernel(uint8_t *out, uint
 //   u8 : chunk = one channel (16 cells)            16 chunks / board
 //   f16: chunk = half a channel (8 cells)          32 chunks / board
 //   f32: chunk = one row of one channel (4 cells)  64 chunks / board
+// the observation is written once and read by somebody else's kernel: streaming (nt) stores
+__device__ __forceinline__ void store_chunk_nt(uint4 *out, uint64_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const u32x4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out) + g);
+}
+
 template <int OBS>
 __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict__ boards, uint64_t chunks,
                                                         uint4 *__restrict__ out)
@@ -539,8 +546,8 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
         const uint64_t board = g >> 4;
         const uint32_t splat = static_cast<uint32_t>(g & 15u) * 0x01010101u;
         const uint4 v = boards[board];
-        out[g] = make_uint4(z80(v.x ^ splat) >> 7, z80(v.y ^ splat) >> 7, z80((v.z & kCellBits) ^ splat) >> 7,
-                            z80((v.w & kCellBits) ^ splat) >> 7);
+        store_chunk_nt(out, g, z80(v.x ^ splat) >> 7, z80(v.y ^ splat) >> 7, z80((v.z & kCellBits) ^ splat) >> 7,
+                       z80((v.w & kCellBits) ^ splat) >> 7);
     } else if constexpr (OBS == 1) {
         const uint64_t board = g >> 5;
         const uint32_t c = static_cast<uint32_t>(g >> 1) & 15u, half = static_cast<uint32_t>(g) & 1u;
@@ -551,7 +558,7 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
             h[k] = (((r0 >> (8 * k)) & 0xffu) == c) ? 0x3c00u : 0u; // fp16 1.0
             h[4 + k] = (((r1 >> (8 * k)) & 0xffu) == c) ? 0x3c00u : 0u;
         }
-        out[g] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        store_chunk_nt(out, g, h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
     } else {
         const uint64_t board = g >> 6;
         const uint32_t c = static_cast<uint32_t>(g >> 2) & 15u, row = static_cast<uint32_t>(g) & 3u;
@@ -560,7 +567,7 @@ __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             f[k] = (((r >> (8 * k)) & 0xffu) == c) ? 0x3f800000u : 0u; // fp32 1.0
-        out[g] = make_uint4(f[0], f[1], f[2], f[3]);
+        store_chunk_nt(out, g, f[0], f[1], f[2], f[3]);
     }
 }
 
