@@ -592,6 +592,22 @@ int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, vo
     return G2048_OK;
 }
 
+// numpy-RNG mode state: the five PCG64 planes plus the per-wavefront lists of finished boards, one allocation
+static int ensure_numpy_rng(g2048_engine *e)
+{
+    if (e->st.rng)
+        return G2048_OK;
+    void *p = nullptr;
+    const size_t bytes = g2048::numpy_rng_bytes(e->n);
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess)
+        return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    e->st.rng = static_cast<uint64_t *>(p);
+    e->st.term_list = reinterpret_cast<uint32_t *>(e->st.rng + 5 * e->n);
+    e->st.term_count = e->st.term_list + ((e->n + 63) / 64) * 64;
+    return G2048_OK;
+}
+
 int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
 {
     if (!e)
@@ -601,15 +617,12 @@ int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
         if (e->st.rng)
             G2048_HIP(hipFree(e->st.rng));
         e->st.rng = nullptr;
+        e->st.term_list = nullptr;
+        e->st.term_count = nullptr;
         return G2048_OK;
     }
-    if (!e->st.rng) {
-        void *p = nullptr;
-        hipError_t err = hipMalloc(&p, e->n * 40);
-        if (err != hipSuccess)
-            return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)(e->n * 40), hipGetErrorString(err));
-        e->st.rng = static_cast<uint64_t *>(p);
-    }
+    if (int rc = ensure_numpy_rng(e))
+        return rc;
     return copy_in(e, e->st.rng, planes, e->n * 40, stream);
 }
 
@@ -617,13 +630,8 @@ int g2048_seed_numpy(g2048_engine *e, uint64_t base_seed, void *stream)
 {
     if (int rc = g2048_seed(e, base_seed, stream))
         return rc;
-    if (!e->st.rng) {
-        void *p = nullptr;
-        hipError_t err = hipMalloc(&p, e->n * 40);
-        if (err != hipSuccess)
-            return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)(e->n * 40), hipGetErrorString(err));
-        e->st.rng = static_cast<uint64_t *>(p);
-    }
+    if (int rc = ensure_numpy_rng(e))
+        return rc;
     G2048_HIP(g2048::launch_seed_numpy(e->st.rng, static_cast<uint32_t>(e->n), base_seed + e->board_offset,
                                        static_cast<hipStream_t>(stream)));
     return G2048_OK;

@@ -17,7 +17,19 @@ struct DeviceState {
     unsigned long long *ep_counters; // two per 64 boards: {finished episodes, of which ended on an illegal move},
                                      // bumped with 64-bit atomics by ONE lane of a wavefront that finished episodes
     uint64_t *rng;      // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
+    // numpy-RNG mode only (same allocation, behind the planes): the boards whose episode ended in the current step,
+    // one list of up to 64 local board indices per wavefront of the step launch + its length.  The step kernel
+    // fills them, reset_list_numpy_kernel consumes them in the same g2048_step call.
+    uint32_t *term_list;  // [ceil(n / 64)][64]
+    uint32_t *term_count; // [ceil(n / 64)]
 };
+
+// bytes of the numpy-RNG allocation for n boards: 5 planes of uint64, the lists, the counts
+inline size_t numpy_rng_bytes(uint64_t n)
+{
+    const uint64_t waves = (n + 63) / 64;
+    return static_cast<size_t>(n * 40 + waves * 64 * 4 + waves * 4);
+}
 
 struct StepArgs {
     DeviceState st;

@@ -301,6 +301,11 @@ __device__ __forceinline__ void store_rng(uint64_t *planes, uint32_t n, uint32_t
     planes[4ull * n + i] = r.buf; // inc never changes
 }
 
+// Step WITHOUT the auto-reset: a spawn in this mode is ~1 500 VALU instructions (the 15-swap Fisher-Yates shuffle
+// over 32-bit draws of a 128-bit LCG), and a reset is two of them -- run in-lane it would be executed by 99 %
+// of the wavefronts for the 7 % of boards that need it.  The boards whose episode ended are instead COMPACTED:
+// every wavefront writes their local indices to its own list (no atomics: slot = wave * 64 + rank among the
+// finished lanes), and reset_list_numpy_kernel, launched right behind, gives one lane to every listed board.
 template <int ACT>
 __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
 {
@@ -318,10 +323,12 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     else
         action = load_action<ACT>(p.actions, i, 0u);
 
-    StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, p.auto_reset != 0);
+    StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, false);
 
+    const bool fin = r.terminated && valid;
+    const Board rec = make_record(bd, static_cast<uint32_t>(score)); // the terminal record where fin
     if (valid) {
-        store_board(p.st.boards, i, make_record(bd, static_cast<uint32_t>(score)));
+        store_board(p.st.boards, i, rec);
         store_rng(p.st.rng, p.n, i, rng);
         if (p.reward)
             p.reward[i] = r.reward;
@@ -333,11 +340,57 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
             p.highest[i] = static_cast<uint8_t>(highest(r.terminal));
     }
     uint32_t episodes = 0, illegal_ends = 0;
-    // (this mode carries the score unpacked; the terminal record is packed only where an episode ended)
-    const bool fin = r.terminated && valid;
-    const Board terminal = g2048_any(fin) ? make_record(r.terminal, static_cast<uint32_t>(r.terminal_score)) : r.terminal;
-    record_episode_ends(p, i, fin, r.illegal, terminal, episodes, illegal_ends);
+    record_episode_ends(p, i, fin, r.illegal, rec, episodes, illegal_ends);
     flush_episode_counts(counters, episodes, illegal_ends);
+    // ---- hand the finished boards to reset_list_numpy_kernel
+    const unsigned long long done = __builtin_amdgcn_ballot_w64(fin && p.auto_reset != 0);
+    const uint32_t wave = i_raw >> 6;
+    if (fin && p.auto_reset != 0) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(done), 0u));
+        p.st.term_list[wave * 64u + rank] = i;
+    }
+    if ((threadIdx.x & 63u) == 0u && i_raw < p.n) // (a wavefront that lies wholly past the end has no list)
+        p.st.term_count[wave] = static_cast<uint32_t>(__popcll(done));
+}
+
+// The `if terminated: env.reset()` of numpy-RNG mode (game2048_env.py:102-111) for the boards the step kernel
+// listed: one wavefront serves the lists of kListGroup step wavefronts (63 boards expected under a random
+// policy), one lane per listed board, so the two expensive spawns run with nearly every lane busy.
+constexpr uint32_t kListGroup = 16;
+
+__global__ void __launch_bounds__(64) reset_list_numpy_kernel(const StepArgs p, uint32_t n_waves)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t first = blockIdx.x * kListGroup;
+    uint32_t pre[kListGroup + 1];
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < kListGroup; ++g) {
+        pre[g] = total;
+        total += (first + g < n_waves) ? p.st.term_count[first + g] : 0u; // uniform addresses: scalar loads
+    }
+    pre[kListGroup] = total;
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t e = base + lane;
+        if (e >= total)
+            continue;
+        uint32_t src = 0;
+#pragma unroll
+        for (uint32_t g = 1; g < kListGroup; ++g)
+            src = e >= pre[g] ? g : src;
+        uint32_t start = 0;
+#pragma unroll
+        for (uint32_t g = 1; g < kListGroup; ++g)
+            start = src == g ? pre[g] : start;
+        const uint32_t i = p.st.term_list[(first + src) * 64u + (e - start)];
+        Pcg64 rng = load_rng(p.st.rng, p.n, i);
+        Board bd{{0u, 0u, 0u, 0u}};   // :104
+        add_tile_numpy(bd, rng);      // :108
+        add_tile_numpy(bd, rng);      // :109
+        store_rng(p.st.rng, p.n, i, rng);
+        store_board(p.st.boards, i, make_record(bd, 0u)); // :105 score = 0
+    }
 }
 
 // numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.
@@ -829,6 +882,10 @@ hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s)
     case 2: hipLaunchKernelGGL(step_numpy_kernel<2>, g, b, 0, s, a); break;
     case 3: hipLaunchKernelGGL(step_numpy_kernel<3>, g, b, 0, s, a); break;
     default: return hipErrorInvalidValue;
+    }
+    if (a.auto_reset) { // the resets of the boards that finished, compacted (see step_numpy_kernel)
+        const uint32_t n_waves = (a.n + 63u) / 64u;
+        hipLaunchKernelGGL(reset_list_numpy_kernel, dim3((n_waves + kListGroup - 1u) / kListGroup), dim3(64), 0, s, a, n_waves);
     }
     return hipGetLastError();
 }

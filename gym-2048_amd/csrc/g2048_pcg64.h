@@ -11,7 +11,7 @@
 //   shuffle  : for i = 15 .. 1: j = interval(i); swap(pos[i], pos[j])   [_generator.pyx, untyped path]
 //   interval : masked rejection on next32                        [distributions.c random_interval]
 // With it, board i plays bit-for-bit the game the unmodified reference env plays after
-// reset(seed = s + i) (tests/golden/traj_numpy_*.npz).  It costs ~5x the spawn-stream mode (about
+// reset(seed = s + i) (tests/golden/traj_numpy_*.npz).  It costs ~9x the spawn-stream mode (about
 // ten 128-bit LCG steps per spawn, divergent rejection loops, 40 B/board of RNG state per step) and
 // exists for fidelity, not for the benchmark.
 #pragma once
