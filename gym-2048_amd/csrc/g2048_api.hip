@@ -88,17 +88,6 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
     return a;
 }
 
-int check_io(const g2048_step_io *io)
-{
-    if (!io)
-        return fail(G2048_ERR_INVALID, "io is NULL");
-    if (io->action_dtype < G2048_ACT_RANDOM || io->action_dtype > G2048_ACT_I64)
-        return fail(G2048_ERR_INVALID, "unknown action_dtype %d", io->action_dtype);
-    if (io->action_dtype != G2048_ACT_RANDOM && !io->actions)
-        return fail(G2048_ERR_INVALID, "actions is NULL but action_dtype is %d", io->action_dtype);
-    return G2048_OK;
-}
-
 size_t action_size(int dtype)
 {
     switch (dtype) {
@@ -107,6 +96,22 @@ size_t action_size(int dtype)
     case G2048_ACT_I64: return 8;
     default: return 0;
     }
+}
+
+int check_io(const g2048_step_io *io)
+{
+    if (!io)
+        return fail(G2048_ERR_INVALID, "io is NULL");
+    if (io->action_dtype < G2048_ACT_RANDOM || io->action_dtype > G2048_ACT_I64)
+        return fail(G2048_ERR_INVALID, "unknown action_dtype %d", io->action_dtype);
+    if (io->action_dtype != G2048_ACT_RANDOM && !io->actions)
+        return fail(G2048_ERR_INVALID, "actions is NULL but action_dtype is %d", io->action_dtype);
+    // the kernels use natural-width loads and stores
+    if ((reinterpret_cast<uintptr_t>(io->actions) & (action_size(io->action_dtype) ? action_size(io->action_dtype) - 1 : 0)) ||
+        (reinterpret_cast<uintptr_t>(io->reward) & 3u) || (reinterpret_cast<uintptr_t>(io->terminal_boards) & 15u))
+        return fail(G2048_ERR_INVALID, "misaligned buffer: actions need their element size, reward 4 bytes, "
+                                       "terminal_boards 16 bytes");
+    return G2048_OK;
 }
 
 } // namespace

@@ -198,3 +198,21 @@ def test_collective_behind_the_c_abi_one_rank(torch_cuda):
     _lib.check(lib.g2048_allgather_returns_local(engines, 1, outs, None))
     assert np.array_equal(out2.cpu().numpy(), want)
     assert lib.g2048_comm_create(2, 5, ident, 0, C.byref(comm)) != 0     # rank out of range
+
+
+def test_misaligned_buffers_are_refused(torch_cuda):
+    torch = torch_cuda
+    from gym2048_amd import _lib
+    from gym2048_amd.batched import Batched2048
+    e = Batched2048(256, seed=1)
+    e.reset()
+    buf = torch.zeros(256 * 4 + 64, dtype=torch.uint8, device=e.device)
+    io = _lib.StepIO()
+    io.action_dtype = _lib.ACT_RANDOM
+    io.reward = buf.data_ptr() + 2                     # float32 output on a 2-byte boundary
+    assert e._lib.g2048_step(e._h, C.byref(io), 1, None) == -1 and b"misaligned" in e._lib.g2048_last_error()
+    io.reward, io.terminal_boards = None, buf.data_ptr() + 8
+    assert e._lib.g2048_step(e._h, C.byref(io), 1, None) == -1
+    io.terminal_boards, io.actions, io.action_dtype = None, buf.data_ptr() + 4, _lib.ACT_I64
+    assert e._lib.g2048_step(e._h, C.byref(io), 1, None) == -1
+    assert e.clock == 0                                 # nothing was stepped
