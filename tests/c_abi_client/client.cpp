@@ -1,0 +1,98 @@
+// client.cpp -- TEST: a caller of libg2048_hip.so that knows nothing but include/g2048.h (no Python, no torch).
+// It plays the benchmark's random-policy rollout through the C ABI with raw hipMalloc'ed I/O buffers and checks
+// every board, reward, flag, score and episodic return against the CPU oracle (oracle/g2048_oracle.h, linked
+// here as the checker).  Built by __graft_entry__.build() with hipcc; run by tests/test_gpu_abi_surface.py.
+//   usage: client [n_boards] [steps] [seed] [board_offset]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/g2048.h"
+#include "../../oracle/g2048_oracle.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("FAIL %s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define G_OK(x) do { int rc_ = (x); if (rc_ != G2048_OK) { std::printf("FAIL %s: %d %s\n", #x, rc_, g2048_last_error()); return 3; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 5000;
+    const uint32_t steps = argc > 2 ? static_cast<uint32_t>(std::atoi(argv[2])) : 40;
+    const uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 42;
+    const uint64_t offset = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 0;
+
+    g2048_engine *eng = nullptr;
+    G_OK(g2048_create(n, 0, seed, offset, &eng));
+    G_OK(g2048_set_illegal_move_reward(eng, -1.0f));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    uint8_t *d_actions, *d_term;
+    float *d_reward;
+    HIP_OK(hipMalloc(&d_actions, n * steps));
+    HIP_OK(hipMalloc(&d_term, n * steps));
+    HIP_OK(hipMalloc(&d_reward, n * steps * sizeof(float)));
+    G_OK(g2048_reset(eng, 0, 0, nullptr, stream));
+    G_OK(g2048_fill_random_actions(eng, 1, steps, d_actions, stream)); // transactions 1 .. steps
+    g2048_step_io io{};
+    io.actions = d_actions;
+    io.action_dtype = G2048_ACT_U8;
+    io.reward = d_reward;
+    io.terminated = d_term;
+    G_OK(g2048_rollout(eng, steps, &io, n, 1, stream));                // k launches, [k][n] buffers, auto-reset
+
+    std::vector<uint8_t> boards(n * 16), term(n * steps), actions(n * steps);
+    std::vector<int32_t> scores(n), returns(n);
+    std::vector<float> reward(n * steps);
+    G_OK(g2048_get_boards(eng, boards.data(), stream));                // host buffers: synchronous
+    G_OK(g2048_get_scores(eng, scores.data(), stream));
+    G_OK(g2048_get_last_scores(eng, returns.data(), stream));
+    HIP_OK(hipMemcpy(term.data(), d_term, n * steps, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(actions.data(), d_actions, n * steps, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(reward.data(), d_reward, n * steps * sizeof(float), hipMemcpyDeviceToHost));
+    g2048_stats st{};
+    G_OK(g2048_episode_stats(eng, &st, stream));
+
+    // ---- the checker: the CPU oracle on the same seed, offset and actions
+    std::vector<uint8_t> o_boards(n * 16), o_term(n), o_ill(n);
+    std::vector<int32_t> o_score(n), o_last(n), o_len(n);
+    std::vector<uint32_t> o_start(n), o_count(n);
+    std::vector<float> o_reward(n);
+    g2048o_batch b{};
+    b.boards = o_boards.data(); b.score = o_score.data(); b.ep_start = o_start.data();
+    b.reward = o_reward.data(); b.terminated = o_term.data(); b.illegal = o_ill.data();
+    b.last_score = o_last.data(); b.last_len = o_len.data(); b.ep_count = o_count.data();
+    g2048o_reset_batch(&b, n, seed, 0, offset, 0, 0);
+    uint64_t episodes = 0, illegal_ends = 0;
+    for (uint32_t j = 0; j < steps; ++j) {
+        b.actions = actions.data() + static_cast<size_t>(j) * n;
+        g2048o_step_batch(&b, n, seed, 1 + j, offset, -1.0f, 0, 1, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (b.actions[i] != g2048o_random_action(seed, 1 + j, static_cast<uint32_t>(offset + i))) {
+                std::printf("FAIL action step %u board %llu\n", j, (unsigned long long)i);
+                return 1;
+            }
+            if (reward[static_cast<size_t>(j) * n + i] != o_reward[i] || term[static_cast<size_t>(j) * n + i] != o_term[i]) {
+                std::printf("FAIL reward/terminated step %u board %llu\n", j, (unsigned long long)i);
+                return 1;
+            }
+            episodes += o_term[i];
+            illegal_ends += o_term[i] && o_ill[i];
+        }
+    }
+    if (std::memcmp(boards.data(), o_boards.data(), n * 16) || std::memcmp(scores.data(), o_score.data(), n * 4) ||
+        std::memcmp(returns.data(), o_last.data(), n * 4)) {
+        std::printf("FAIL final boards / scores / returns differ\n");
+        return 1;
+    }
+    if (st.episodes != episodes || st.illegal_ends != illegal_ends) {
+        std::printf("FAIL episode counters %llu/%llu vs %llu/%llu\n", (unsigned long long)st.episodes,
+                    (unsigned long long)st.illegal_ends, (unsigned long long)episodes, (unsigned long long)illegal_ends);
+        return 1;
+    }
+    G_OK(g2048_destroy(eng));
+    std::printf("OK %llu boards x %u steps through the C ABI == oracle; %llu episodes\n", (unsigned long long)n, steps,
+                (unsigned long long)episodes);
+    return 0;
+}

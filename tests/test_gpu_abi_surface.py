@@ -216,3 +216,15 @@ def test_misaligned_buffers_are_refused(torch_cuda):
     io.terminal_boards, io.actions, io.action_dtype = None, buf.data_ptr() + 4, _lib.ACT_I64
     assert e._lib.g2048_step(e._h, C.byref(io), 1, None) == -1
     assert e.clock == 0                                 # nothing was stepped
+
+
+@pytest.mark.parametrize("args", [("5000", "40", "42", "0"), ("65536", "24", "7", str((1 << 32) - 65536))])
+def test_pure_c_client_of_the_abi(torch_cuda, args):
+    """tests/c_abi_client/client.cpp: includes only include/g2048.h (+ the oracle's header as checker), raw
+    hipMalloc'ed buffers, g2048_create / reset / fill_random_actions / rollout / get_* / episode_stats, and
+    compares everything with the C oracle itself -- the C ABI is usable without Python or torch."""
+    import subprocess
+    import __graft_entry__ as ge
+    exe = ge.build_c_client()
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
