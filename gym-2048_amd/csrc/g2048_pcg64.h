@@ -11,7 +11,7 @@
 //   shuffle  : for i = 15 .. 1: j = interval(i); swap(pos[i], pos[j])   [_generator.pyx, untyped path]
 //   interval : masked rejection on next32                        [distributions.c random_interval]
 // With it, board i plays bit-for-bit the game the unmodified reference env plays after
-// reset(seed = s + i) (tests/golden/traj_numpy_*.npz).  It costs ~9x the spawn-stream mode (about
+// reset(seed = s + i) (tests/golden/traj_numpy_*.npz).  It costs ~7x the spawn-stream mode (about
 // ten 128-bit LCG steps per spawn, divergent rejection loops, 40 B/board of RNG state per step) and
 // exists for fidelity, not for the benchmark.
 #pragma once
@@ -84,19 +84,33 @@ G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
 {
     const uint32_t exp = ((pcg64_next64(r) >> 11) < kTwoThreshold53) ? 1u : 2u; // :168
     uint64_t pos = 0xFEDCBA9876543210ull;                                       // :169 nibble i = position i
-    // :170 Generator.shuffle: for i = 15 .. 1: j = random_interval(i); swap(pos[i], pos[j]).  Written as
-    // ONE loop over 32-bit draws in which every lane keeps its own i: a lane whose masked draw is
-    // rejected (v > i) simply keeps i for the next draw.  The draws each lane consumes are exactly
-    // numpy's, but the wavefront iterates max-over-lanes of the TOTAL draws (~30) instead of the sum over
-    // i of max-over-lanes of the per-i rejections (~60).
-    for (uint32_t i = 15; i >= 1;) {
+    // :170 Generator.shuffle: for i = 15 .. 1: j = random_interval(i); swap(pos[i], pos[j]), random_interval
+    // being masked rejection on 32-bit draws (a rejected draw, v > i, simply leaves i for the next draw).
+    // numpy serves 32-bit draws as the two halves of one 64-bit output, low half first, the high half buffered.
+    // The loop below keeps the wavefront in LOCKSTEP on the 128-bit LCG: a lane first uses up a half that was
+    // buffered before the call, then every iteration is ONE LCG step and TWO draws, and a lane that finishes
+    // on a low half leaves the high half in the buffer -- the draws each lane consumes are exactly numpy's.
+    uint32_t i = 15;
+    auto consume = [&](uint32_t draw) {
         const uint32_t mask = i >= 8u ? 15u : (i >= 4u ? 7u : (i >= 2u ? 3u : 1u));
-        const uint32_t j = pcg64_next32(r) & mask;
+        const uint32_t j = draw & mask;
         if (j <= i) {
             const uint64_t d = ((pos >> (4u * i)) ^ (pos >> (4u * j))) & 15ull; // swap nibbles i and j
             pos ^= (d << (4u * i)) | (d << (4u * j));
             --i;
         }
+    };
+    if (r.buf >> 32) {
+        consume((uint32_t)r.buf);
+        r.buf = 0;
+    }
+    while (i >= 1u) {
+        const uint64_t next = pcg64_next64(r);
+        consume((uint32_t)next);
+        if (i >= 1u)
+            consume((uint32_t)(next >> 32));
+        else
+            r.buf = (next >> 32) | (1ull << 32);
     }
     const uint32_t empty = empty_mask16(bd);
     uint32_t p = 0;
