@@ -205,3 +205,52 @@ def test_more_than_4_gib_of_records(torch_cuda):
     st = big.episode_stats()
     assert st["episodes"] > n // 2 and sum(st["highest_hist"]) == n
     big.close()
+
+
+def test_numpy_rng_mode_at_scale_and_with_every_board_resetting(torch_cuda):
+    """numpy-RNG mode compacts the boards that finished into per-wavefront lists and resets them in a second
+    kernel.  (1) 2^18 boards x 20 steps of the synthetic policy against the oracle's numpy mode (RNG states
+    included); (2) the worst case for the lists: EVERY board makes an illegal move in the same step (64 entries
+    per wavefront, 1 024 per list group), with a ragged board count."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed = 1 << 18, 9
+    eng = Batched2048(n, seed=seed, rng="numpy")
+    ob = OracleBatch(n, seed, threads=0)
+    ob.seed_numpy(seed)
+    eng.reset()
+    ob.reset_numpy()
+    for s in range(20):
+        eng.step(None)
+        ob.step_numpy(None)
+        assert np.array_equal(eng.reward.cpu().numpy(), ob.reward), s
+        assert np.array_equal(eng.terminated.cpu().numpy(), ob.terminated), s
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ob.boards) and np.array_equal(eng.get_scores(), ob.score)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng) and np.array_equal(eng.get_last_scores(), ob.last_score)
+    # (2) tiles packed against the top edge: "up" is illegal for every board
+    n2 = 70000 + 37
+    eng2 = Batched2048(n2, seed=seed + 1, rng="numpy", illegal_move_reward=-2.0)
+    ob2 = OracleBatch(n2, seed + 1, threads=0)
+    ob2.illegal_move_reward = -2.0
+    ob2.seed_numpy(seed + 1)
+    eng2.reset()
+    ob2.reset_numpy()
+    stuck = np.zeros((n2, 16), np.uint8)
+    stuck[:, :4] = (1, 2, 3, 4)
+    stuck[:, 4] = np.arange(n2) % 5                      # some variety below the top row (still no upward move)
+    stuck[stuck[:, 4] == 1, 4] = 2                       # (a 2 under a 2 would merge upwards)
+    eng2.set_boards(stuck)
+    ob2.boards[:] = stuck
+    up = np.zeros(n2, np.uint8)
+    eng2.step(torch.as_tensor(up))
+    ob2.step_numpy(up)
+    assert ob2.terminated.all() and ob2.illegal.all()
+    assert np.array_equal(eng2.terminated.cpu().numpy(), ob2.terminated) and (eng2.reward.cpu().numpy() == -2.0).all()
+    assert np.array_equal(eng2.get_boards().reshape(n2, 16), ob2.boards)
+    assert np.array_equal(eng2.get_numpy_rng().T, ob2.rng)
+    assert (eng2.get_scores() == 0).all() and eng2.episode_stats()["illegal_ends"] == n2
+    for s in range(6):                                   # and play on from there
+        eng2.step(None)
+        ob2.step_numpy(None)
+    assert np.array_equal(eng2.get_boards().reshape(n2, 16), ob2.boards) and np.array_equal(eng2.get_numpy_rng().T, ob2.rng)
