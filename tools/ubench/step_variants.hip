@@ -9,9 +9,9 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../gym-2048_amd/csrc/g2048_kernels.hip" // the product kernels themselves (variant "prod")
+#include "_v1/g2048_kernels.hip" // the ROUND-1 kernels (git e7a8169, namespace g2048v1; tools/ubench/build.sh): this harness documents round 1 // the product kernels themselves (variant "prod")
 
-using namespace g2048;
+using namespace g2048v1;
 static StepArgs g_prod;   // product-kernel arguments, filled in main()
 static int g_prod_outputs = 1;
 

@@ -5,8 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../gym-2048_amd/csrc/g2048_kernels.hip"
-using namespace g2048;
+#include "_v1/g2048_kernels.hip" // the ROUND-1 kernels (git e7a8169, namespace g2048v1; tools/ubench/build.sh): this harness documents round 1
+using namespace g2048v1;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char **argv)
