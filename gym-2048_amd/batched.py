@@ -501,9 +501,20 @@ class Batched2048:
         self._fresh = False
 
     def render(self, index: int = 0, mode: str = "ansi"):
+        """game2048_env.py:113-163 for board ``index``: only that board's 16-byte record crosses PCIe."""
         from .render import render_board
-        vals = exp_to_values(self.get_boards()[index])
-        return render_board(vals, int(self.get_scores()[index]), mode)
+        cells, score = decode_record(self.records()[int(index)].cpu().numpy())
+        return render_board(exp_to_values(cells.reshape(4, 4)), score, mode)
+
+
+def decode_record(raw) -> tuple:
+    """Host-side reading of one 16-byte board record (include/g2048.h): ``(cells uint8[16], score)`` with
+    score = potential - deficit mod 2^24, potential = sum of (e - 1) * 2^e over the tiles."""
+    raw = np.asarray(raw, dtype=np.uint8).reshape(16)
+    cells = raw & 0x1F
+    deficit = sum(((int(raw[8 + k // 3]) >> (5 + k % 3)) & 1) << k for k in range(24))
+    potential = sum((int(e) - 1) << int(e) for e in cells if e)
+    return cells, (potential - deficit) & 0xFFFFFF
 
 
 def parse_stats(raw) -> dict:

@@ -228,3 +228,21 @@ def test_pure_c_client_of_the_abi(torch_cuda, args):
     exe = ge.build_c_client()
     out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+def test_host_side_record_decoding_and_render(torch_cuda):
+    """decode_record (Python reading of the record format) == the device's export kernels; render() of one board
+    of a big batch moves 16 bytes, and prints what the single-env renderer prints."""
+    from gym2048_amd.batched import Batched2048, decode_record, exp_to_values
+    from gym2048_amd.render import render_board
+    n = 1 << 16
+    eng = Batched2048(n, seed=12)
+    eng.reset()
+    eng.rollout(300)
+    boards, scores, raw = eng.get_boards().reshape(n, 16), eng.get_scores(), eng.records().cpu().numpy()
+    for i in list(range(0, n, 997)) + [n - 1]:
+        cells, score = decode_record(raw[i])
+        assert np.array_equal(cells, boards[i]) and score == scores[i]
+    i = int(np.argmax(scores))
+    want = render_board(exp_to_values(boards[i].reshape(4, 4)), int(scores[i]), "ansi").getvalue()
+    assert eng.render(i, "ansi").getvalue() == want and eng.render(i, "rgb_array").shape == (280, 280, 3)
