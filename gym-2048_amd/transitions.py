@@ -143,6 +143,25 @@ class Transitions:
                            np.tile(self.reward.reshape(-1), 8), exp_to_values(no.cpu().numpy()).reshape(-1, 4, 4),
                            np.tile(self.done.reshape(-1), 8))
 
+    # ------------------------------------------------------------------ rewards from (board, action)
+    def recompute_rewards(self, device=0, illegal_move_reward=0.0):
+        """add_rewards_to_training_data.py:55-68 for every row at once: the reward ``env.step(action)`` gives from
+        ``env.set_board(board)`` -- the merge score of the move, or ``illegal_move_reward`` where the move is
+        illegal (game2048_env.py:85-95).  One ``g2048_move(trial)`` launch over all rows; returns a new
+        ``Transitions`` with the rewards filled in (boards, actions, next boards, done flags unchanged)."""
+        import torch
+
+        from .batched import Batched2048
+        n = self.size()
+        eng = Batched2048(n, device=device)
+        try:
+            eng.set_boards(values_to_exp(self.x).reshape(n, 16))
+            score, legal = eng.move(torch.as_tensor(self.action.reshape(n).astype(np.uint8)), trial=True)
+            reward = np.where(legal.cpu().numpy().astype(bool), score.cpu().numpy().astype(float), float(illegal_move_reward))
+        finally:
+            eng.close()
+        return Transitions(self.x, self.action, reward, self.next_x, self.done)
+
     # ------------------------------------------------------------------ canonicalisation on the device
     def canonicalize(self, device=0):
         """Symmetric-board canonicalisation (the inverse view of ``augment``): every row is

@@ -394,6 +394,28 @@ def gen_canonical_table(rng, n=1024):
                 canon_next=np.array(canon_nx, np.uint8).reshape(n, 16), symmetry=np.array(sym, np.uint8))
 
 
+def gen_rewards_table(ref, rng, n=600):
+    """add_rewards_to_training_data.py:55-59 (get_reward_for_state_action): reward of env.step(action) from a
+    set board, for random (board, action) pairs incl. illegal moves, with the default and a negative
+    illegal_move_reward.  Computed by the reference env itself."""
+    boards = random_boards(rng, n, max_exp=12)
+    actions = rng.integers(0, 4, n)
+    out = {}
+    for tag, irw in (("default", None), ("minus1", -1.0)):
+        env = ref.Game2048Env()
+        if irw is not None:
+            env.set_illegal_move_reward(irw)
+        rewards = np.zeros(n, np.float64)
+        for i in range(n):
+            env.reset()
+            env.set_board(np.where(boards[i] > 0, 1 << boards[i].astype(np.int64), 0).reshape(4, 4))
+            _, reward, _, _, _ = env.step(int(actions[i]))
+            rewards[i] = reward
+        out["rewards_" + tag] = rewards
+    out.update(boards=boards.astype(np.uint8), actions=actions.astype(np.uint8))
+    return out
+
+
 def gen_reference_test_kats(ref):
     """Re-capture, by calling the reference, the values its own unit tests pin
     (test_game2048_env.py:13-34 shift rows, :40-98 move board, :113-151 isend, :165-217 step)."""
@@ -577,6 +599,7 @@ def main():
         return
     if args.only_round2:
         save("traj_corner_deep.npz", gen_trajectories(ref, "corner_deep", 31, 48, 1024, "corner"))
+        save("rewards_table.npz", gen_rewards_table(ref, np.random.default_rng(9)))
         save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
         save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
         print("\n".join(report))
@@ -602,6 +625,7 @@ def main():
                                                     max_tile=256))
     save("traj_noautoreset.npz", gen_trajectories(ref, "noautoreset", 5, 16, 96, "random", auto_reset=False))
     save("traj_corner_deep.npz", gen_trajectories(ref, "corner_deep", 31, 48, 1024, "corner"))
+    save("rewards_table.npz", gen_rewards_table(ref, np.random.default_rng(9)))
     save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
     save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
     validate(ref, args.validate_steps, report)

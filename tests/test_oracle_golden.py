@@ -206,3 +206,16 @@ def test_render_ansi_matches_the_reference_text():
         vals = np.where(e > 0, 1 << e.astype(np.int64), 0).reshape(4, 4)
         got = render_board(vals, int(score) if is_int else float(score), "ansi").getvalue()
         assert got == str(text)
+
+
+def test_oracle_rewards_match_the_reference_add_rewards_table(oracle_lib):
+    """add_rewards_to_training_data.py:55-59 captured from the reference env: the oracle's move() gives the same
+    reward for every (board, action), legal or not."""
+    t = load_golden("rewards_table")
+    I64x16 = C.c_int64 * 16
+    for tag, irw in (("default", 0.0), ("minus1", -1.0)):
+        for b, a, want in zip(t["boards"], t["actions"], t["rewards_" + tag]):
+            M, sc = I64x16(*[0 if e == 0 else 1 << int(e) for e in b]), C.c_int64()
+            legal = oracle_lib.g2048o_move(M, int(a), 1, C.byref(sc))
+            assert (float(sc.value) if legal else irw) == want
+    assert (t["rewards_minus1"] == -1.0).sum() >= 10         # the table contains illegal moves

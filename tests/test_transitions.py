@@ -83,3 +83,14 @@ def test_record_rollout_transitions_are_consistent_with_the_oracle(torch_cuda):
     assert n_done > 50
     text = t.to_csv_text()
     assert text.count("\n") == t.size() + 1
+
+
+@pytest.mark.gpu
+def test_recompute_rewards_matches_the_reference_add_rewards_script(torch_cuda):
+    """Transitions.recompute_rewards == add_rewards_to_training_data.get_reward_for_state_action run by the
+    reference env (tests/golden/rewards_table.npz)."""
+    t = load_golden("rewards_table")
+    vals = np.where(t["boards"] > 0, 1 << t["boards"].astype(np.int64), 0)
+    tr = Transitions(vals, t["actions"], np.zeros(len(vals)), vals, np.zeros(len(vals), bool))
+    assert np.array_equal(tr.recompute_rewards().reward.reshape(-1), t["rewards_default"])
+    assert np.array_equal(tr.recompute_rewards(illegal_move_reward=-1.0).reward.reshape(-1), t["rewards_minus1"])
