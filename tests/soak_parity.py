@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Soak script (test infrastructure; lives under tests/ because it drives the oracle): the HIP engine against the C oracle for thousands of steps of a legality-aware corner
+policy with a little noise -- long games, tiles of 2^11 and beyond, deficits that carry across many bits.
+    python tests/soak_parity.py [log2_boards=18] [steps=3000] [noise=0.01]"""
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+import __graft_entry__ as ge
+
+ge.build()
+from gym2048_amd.batched import Batched2048
+from oracle import OracleBatch
+
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+noise = float(sys.argv[3]) if len(sys.argv) > 3 else 0.01
+n = 1 << lg
+eng = Batched2048(n, seed=2025, illegal_move_reward=-1.0)
+ora = OracleBatch(n, 2025, threads=0)
+ora.illegal_move_reward = -1.0
+eng.reset()
+ora.reset()
+gen = torch.Generator(device=eng.device)
+gen.manual_seed(1)
+t0 = time.time()
+for s in range(steps):
+    choice = torch.full((n,), 3, dtype=torch.uint8, device=eng.device)
+    found = torch.zeros(n, dtype=torch.bool, device=eng.device)
+    for d in (3, 2, 1, 0):
+        _, legal = eng.move(torch.full((n,), d, dtype=torch.uint8, device=eng.device), trial=True)
+        take = legal.bool() & ~found
+        choice = torch.where(take, torch.full_like(choice, d), choice)
+        found |= take
+    rnd = torch.rand(n, device=eng.device, generator=gen) < noise
+    rand_a = torch.randint(0, 4, (n,), device=eng.device, generator=gen, dtype=torch.uint8)
+    acts = torch.where(rnd, rand_a, choice)
+    eng.step(acts)
+    ora.step(acts.cpu().numpy())
+    assert np.array_equal(eng.reward.cpu().numpy(), ora.reward), s
+    assert np.array_equal(eng.terminated.cpu().numpy(), ora.terminated), s
+    if s % 100 == 99 or s == steps - 1:
+        assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards), s
+        assert np.array_equal(eng.get_scores(), ora.score), s
+        assert np.array_equal(eng.get_last_scores(), ora.last_score), s
+        assert np.array_equal(eng.highest.cpu().numpy(), ora.highest), s
+st = eng.episode_stats()
+assert st["episodes"] == int(ora.ep_count.sum())
+print(f"soak ok: 2^{lg} boards x {steps} steps bit-exact vs oracle in {time.time() - t0:.0f} s; episodes {st['episodes']}, "
+      f"max tile 2^{st['max_exp']}, best last score {st['last_score_max']}, illegal ends {st['illegal_ends']}, "
+      f"highest-tile histogram {[c for c in st['highest_hist'] if c]}")
