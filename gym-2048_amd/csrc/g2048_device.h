@@ -106,8 +106,24 @@ G2048_DEV Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     for (int round = 0; round < 10; ++round) {
         const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
         const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
-        const uint32_t n0 = g2048_xor3((uint32_t)(p1 >> 32), c1, k0);
-        const uint32_t n2 = g2048_xor3((uint32_t)(p0 >> 32), c3, k1);
+        // At every call site c0, c1, c3 and the key are wave-uniform (t, slot, seed) and only c2 (the board) is
+        // per lane.  Rounds 0..2 therefore pair the two uniform terms of each xor3 with plain xors, so they --
+        // and round 1's whole M1 * c2 product -- stay on the scalar unit (one v_xor with an SGPR operand per
+        // word); the bitop3 builtin is VALU-only and would cost a v_mov per second SGPR operand.
+        uint32_t n0, n2;
+        if (round == 0) {
+            n0 = (uint32_t)(p1 >> 32) ^ (c1 ^ k0);
+            n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        } else if (round == 1) {
+            n0 = c1 ^ ((uint32_t)(p1 >> 32) ^ k0);
+            n2 = (uint32_t)(p0 >> 32) ^ (c3 ^ k1);
+        } else if (round == 2) {
+            n0 = (uint32_t)(p1 >> 32) ^ (c1 ^ k0);            // c1 = low word of round 1's uniform product
+            n2 = g2048_xor3((uint32_t)(p0 >> 32), c3, k1);
+        } else {
+            n0 = g2048_xor3((uint32_t)(p1 >> 32), c1, k0);
+            n2 = g2048_xor3((uint32_t)(p0 >> 32), c3, k1);
+        }
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -481,22 +497,23 @@ struct StepOut {
     uint32_t gain;   // merge score of the move (:85); 0 when illegal
     bool legal;      // false = the reference's IllegalMove (:91)
     bool terminated; // :89 / :94
-    Board terminal;  // record after move + spawn, before any auto-reset (valid always; "terminal" when terminated)
+    uint32_t legal_mask; // all-ones when legal (lane-wide select mask, reused by reset_record)
+    Board terminal;  // step_record only: record after move + spawn, before any auto-reset ("terminal" when terminated)
 };
 
-// game2048_env.py:76-100 on one board RECORD, followed -- when auto_reset -- by the caller's
-// `if terminated: env.reset()` (:102-111).  w = Philox block of this transaction: word 0 = the step's
+// play_record: game2048_env.py:76-100 on one board RECORD (no reset: rec is the terminal record when
+// o.terminated).  w = Philox block of this transaction: word 0 = the step's
 // spawn; the reset uses words 1,2 after a legal move and 0,1 after an illegal one (an illegal move
 // consumes no randomness, :91-95).  The score never appears: a merge moves potential and score together,
 // only a spawned 4 touches the deficit.
 template <class Tables>
-G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint32_t max_exp, bool auto_reset,
-                              const Tables &tb)
+G2048_DEV StepOut play_record(Board &rec, uint32_t action, const Words &w, uint32_t max_exp, const Tables &tb)
 {
     StepOut o;
     Board cells = record_cells(rec);
     o.legal = move_sel(cells, tb.move_sel(action), o.gain);        // :85 (illegal: board unchanged, gain 0)
     const uint32_t lm = lanemask(o.legal);
+    o.legal_mask = lm;
     const bool is2 = (w.w[0] & 0xffffu) <= 58982u;                 // :168 the spawn's value
     // :88 add_tile needs an empty cell; a board that changed always has one (a full board can only
     // change by merging).  After an illegal move nothing is spawned (:91-95).
@@ -511,11 +528,29 @@ G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint3
     // a spawned 4 raises the potential without scoring: deficit += 4 (bit 2 of d = bit 7 of byte 8)
     const uint32_t inc = (o.legal && !is2) ? 0x80u : 0u;
     record_update(rec, cells, inc);
+    return o;
+}
+
+// The caller's `if terminated: env.reset()` (:102-111) for a lane whose episode just ended in play_record: a
+// plain divergent branch at the call site -- only the lanes that reset execute it (exec-masked writes straight
+// into the record, no selects), and the wavefront skips it when none does.  The kernels store the terminal
+// record BEFORE calling this, so the fresh record overwrites it in place and no second copy is ever live
+// (four v_mov per lane otherwise; -0.2 us per launch at 2^20 boards, profiles/r02_s_ubench_2p20.txt).
+template <class Tables>
+G2048_DEV void reset_record(Board &rec, const StepOut &o, const Words &w, const Tables &tb)
+{
+    rec = fresh_record_lut(bfi(o.legal_mask, w.w[1], w.w[0]), bfi(o.legal_mask, w.w[2], w.w[1]), tb); // :104-109
+}
+
+// play_record + reset_record in one call, keeping the terminal record in o.terminal (host mirror, tools).
+template <class Tables>
+G2048_DEV StepOut step_record(Board &rec, uint32_t action, const Words &w, uint32_t max_exp, bool auto_reset,
+                              const Tables &tb)
+{
+    StepOut o = play_record(rec, action, w, max_exp, tb);
     o.terminal = rec;
-    // the caller's `if terminated: env.reset()` -- a plain divergent branch: only the lanes that reset execute
-    // it (exec-masked writes straight into the record, no selects), and the wavefront skips it when none does
     if (o.terminated && auto_reset)
-        rec = fresh_record_lut(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]), tb); // :104-109
+        reset_record(rec, o, w, tb);
     return o;
 }
 

@@ -77,8 +77,9 @@ __device__ const uint32_t kWaveTablesImage[128] __attribute__((aligned(16))) = {
 // `x`, but not before `dep` has been computed (pins the s_waitcnt of a load below independent work).
 __device__ __forceinline__ uint2 use_after(uint2 x, uint32_t dep)
 {
-    asm volatile("" : "+v"(x.x), "+v"(x.y) : "v"(dep));
-    return x;
+    unsigned long long both = (static_cast<unsigned long long>(x.y) << 32) | x.x; // ONE 64-bit operand: the pair stays a pair
+    asm volatile("" : "+v"(both) : "v"(dep));
+    return make_uint2(static_cast<uint32_t>(both), static_cast<uint32_t>(both >> 32));
 }
 
 struct LdsTables {
@@ -176,7 +177,7 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
 // One board per lane, one pass: load the 16-byte record + the action -> Philox block (independent of
-// the loads, so it runs while they are in flight) -> step_record (move through the lane's selector row,
+// the loads, so it runs while they are in flight) -> play_record (move through the lane's selector row,
 // spawn, done detection, deficit update, auto-reset through the one-tile table) -> store record, reward,
 // terminated.  No barrier, no cross-wave traffic.
 // FULL: the batch is a whole number of blocks (n % 256 == 0), no lane is past the end.
@@ -197,7 +198,16 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
     const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
 
-    const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
+    const StepOut o = play_record(rec, action, w, p.max_exp, tb);
+
+    // episode ends first: the terminal record goes out before the reset overwrites it in place
+    uint32_t episodes = 0, illegal_ends = 0;
+    record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+    uint32_t top = 0;
+    if (p.highest)
+        top = highest(record_cells(rec));                                                        // :97
+    if (o.terminated && p.auto_reset != 0)
+        reset_record(rec, o, w, tb);
 
     if (valid) {
         store_board_nt(p.st.boards, i, rec);
@@ -208,10 +218,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs p)
         if (p.illegal)
             __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + i);
         if (p.highest)
-            __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(o.terminal))), p.highest + i); // :97
+            __builtin_nontemporal_store(static_cast<uint8_t>(top), p.highest + i);
     }
-    uint32_t episodes = 0, illegal_ends = 0;
-    record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
     flush_episode_counts(counters, episodes, illegal_ends);
 }
 
@@ -231,8 +239,10 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
                                       p.seed_lo, p.seed_hi);
-        const StepOut o = step_record(rec, w.w[3] >> 30, w, p.max_exp, true, tb);
-        record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
+        const StepOut o = play_record(rec, w.w[3] >> 30, w, p.max_exp, tb);
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+        if (o.terminated)
+            reset_record(rec, o, w, tb);
     }
     if (valid)
         store_board(p.st.boards, i, rec);
@@ -268,7 +278,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
             action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(p.actions) + o_idx)) & 3u;
         else
             action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(p.actions) + o_idx)) & 3u;
-        const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
+        const StepOut o = play_record(rec, action, w, p.max_exp, tb);
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
         if (valid) {
             if (p.reward)
                 __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + o_idx);
@@ -277,9 +288,10 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
             if (p.illegal)
                 __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + o_idx);
             if (p.highest)
-                __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(o.terminal))), p.highest + o_idx);
+                __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(rec))), p.highest + o_idx);
         }
-        record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
+        if (o.terminated && p.auto_reset != 0)
+            reset_record(rec, o, w, tb);
     }
     if (valid)
         store_board_nt(p.st.boards, i, rec);

@@ -25,7 +25,7 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
        X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
-       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072 };
+       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144 };
 
 template <class T> __device__ __forceinline__ T *off32(T *base, uint32_t i)
 {
@@ -90,7 +90,18 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     } else
         action = load_action<1>(p.actions, i, 0u);
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
-    const StepOut o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
+    uint32_t episodes = 0, illegal_ends = 0;
+    StepOut o;
+    if (X & X_TERM_FIRST) {
+        // terminal record stored BEFORE the reset overwrites it in place: no second copy of the record is live
+        o = step_record(rec, action, w, p.max_exp, false, tb);
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+        if (o.terminated && p.auto_reset != 0) {
+            const uint32_t lm = lanemask(o.legal);
+            rec = fresh_record_lut(bfi(lm, w.w[1], w.w[0]), bfi(lm, w.w[2], w.w[1]), tb);
+        }
+    } else
+        o = step_record(rec, action, w, p.max_exp, p.auto_reset != 0, tb);
     if (valid && (X & X_OFF32)) {
         const u32x4 v = {rec.r[0], rec.r[1], rec.r[2], rec.r[3]};
         __builtin_nontemporal_store(v, off32(reinterpret_cast<u32x4 *>(p.st.boards), i));
@@ -115,7 +126,6 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
             __builtin_nontemporal_store(bytes, reinterpret_cast<uint32_t *>(p.terminated + (i_raw & ~63u)) + lane);
         }
     }
-    uint32_t episodes = 0, illegal_ends = 0;
     if ((X & X_PREFETCH) && touched == 0x12345677u)
         p.st.ep_counters[0] = touched; // keeps the touch alive
     if (X & (X_LASTREC_DENSE | X_LASTREC_4B | X_LASTREC_RING)) {
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
             episodes += (uint32_t)__popcll(done);
             illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
         }
-    } else if (!(X & X_NO_LASTREC))
+    } else if (!(X & (X_NO_LASTREC | X_TERM_FIRST)))
         record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
     if (!(X & (X_NO_COUNT | X_COUNT_RMW))) {
         if (episodes != 0u && lane == 0u) {
@@ -255,6 +265,7 @@ int main(int argc, char **argv)
     vs.push_back({"v3  step_kernel<1>, no outputs", [&](uint32_t j) { io2(j); a2.reward = nullptr; a2.terminated = nullptr; (void)g2048::launch_step(a2, 1, 0); }});
 
     vs.push_back({"x   copy of the product kernel (sanity: = v3 <1>)", [&](uint32_t j) { io2(j); launch_x<0>(a2); }});
+    vs.push_back({"x   terminal record stored before the in-place reset (no live copy)", [&](uint32_t j) { io2(j); launch_x<X_TERM_FIRST>(a2); }});
     vs.push_back({"x   actions: 16 lanes load a dword, ds_bpermute", [&](uint32_t j) { io2(j); launch_x<X_ACT_PACKED>(a2); }});
     vs.push_back({"x   terminated: ballot -> 16 lanes store a dword", [&](uint32_t j) { io2(j); launch_x<X_TERM_PACKED>(a2); }});
     vs.push_back({"x   both packed", [&](uint32_t j) { io2(j); launch_x<X_ACT_PACKED | X_TERM_PACKED>(a2); }});
