@@ -321,29 +321,44 @@ int main(int argc, char **argv)
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (r > 0) g_us.push_back(ms * 1e3f / launches);
         }
-        // two streams: boards [0, n/2) on cs, [n/2, n) on s2, each its own chain of launches
-        g2048::StepArgs lo = a2, hi = a2;
-        lo.n = hi.n = n / 2; hi.board_offset = n / 2;
-        hi.st.boards = a2.st.boards + n / 2; hi.st.last_record = a2.st.last_record + n / 2; hi.st.ep_counters = a2.st.ep_counters + n / 64;
-        hipEvent_t f0, f1; CHECK(hipEventCreate(&f0)); CHECK(hipEventCreate(&f1));
-        for (int r = 0; r < rounds + 1; ++r) {
-            CHECK(hipEventRecord(e0, cs));
-            CHECK(hipStreamWaitEvent(s2, e0, 0));
-            for (int j = 0; j < launches; ++j) {
-                lo.t_lo = hi.t_lo = 100 + j;
-                lo.actions = actions + (size_t)j * n; hi.actions = actions + (size_t)j * n + n / 2;
-                lo.reward = reward + (size_t)j * n; hi.reward = reward + (size_t)j * n + n / 2;
-                lo.terminated = term + (size_t)j * n; hi.terminated = term + (size_t)j * n + n / 2;
-                CHECK(g2048::launch_step(lo, 1, cs));
-                CHECK(g2048::launch_step(hi, 1, s2));
+        // S streams: boards [q n/S, (q+1) n/S) on stream q, each its own chain of launches
+        hipEvent_t f1[8];
+        hipStream_t ss[8];
+        ss[0] = cs; ss[1] = s2;
+        for (int q = 2; q < 8; ++q) CHECK(hipStreamCreate(&ss[q]));
+        for (int q = 0; q < 8; ++q) CHECK(hipEventCreate(&f1[q]));
+        std::vector<float> s_us[9];
+        for (int S : {2, 4, 8}) {
+            g2048::StepArgs part[8];
+            for (int q = 0; q < S; ++q) {
+                part[q] = a2;
+                part[q].n = n / S; part[q].board_offset = q * (n / S);
+                part[q].st.boards = a2.st.boards + (size_t)q * (n / S);
+                part[q].st.last_record = a2.st.last_record + (size_t)q * (n / S);
+                part[q].st.ep_counters = a2.st.ep_counters + (size_t)q * (n / S / 64) * 2;
             }
-            CHECK(hipEventRecord(f1, s2));
-            CHECK(hipStreamWaitEvent(cs, f1, 0));
-            CHECK(hipEventRecord(e1, cs));
-            CHECK(hipEventSynchronize(e1));
-            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-            if (r > 0) t_us.push_back(ms * 1e3f / launches);
+            for (int r = 0; r < rounds + 1; ++r) {
+                CHECK(hipEventRecord(e0, cs));
+                for (int q = 1; q < S; ++q) CHECK(hipStreamWaitEvent(ss[q], e0, 0));
+                for (int j = 0; j < launches; ++j)
+                    for (int q = 0; q < S; ++q) {
+                        part[q].t_lo = 100 + j;
+                        part[q].actions = actions + (size_t)j * n + (size_t)q * (n / S);
+                        part[q].reward = reward + (size_t)j * n + (size_t)q * (n / S);
+                        part[q].terminated = term + (size_t)j * n + (size_t)q * (n / S);
+                        CHECK(g2048::launch_step(part[q], 1, ss[q]));
+                    }
+                for (int q = 1; q < S; ++q) { CHECK(hipEventRecord(f1[q], ss[q])); CHECK(hipStreamWaitEvent(cs, f1[q], 0)); }
+                CHECK(hipEventRecord(e1, cs));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (r > 0) s_us[S].push_back(ms * 1e3f / launches);
+            }
+            std::sort(s_us[S].begin(), s_us[S].end());
         }
+        t_us = s_us[2];
+        printf("4 streams, a quarter of the batch each:  %.2f us per step   (median), %.2f (min)\n", s_us[4][s_us[4].size() / 2], s_us[4][0]);
+        printf("8 streams, an eighth of the batch each:  %.2f us per step   (median), %.2f (min)\n", s_us[8][s_us[8].size() / 2], s_us[8][0]);
         std::sort(g_us.begin(), g_us.end()); std::sort(t_us.begin(), t_us.end());
         printf("hipGraph replay of %d product launches: %.2f us per launch (median), %.2f (min)\n", launches, g_us[g_us.size() / 2], g_us[0]);
         printf("two streams, half the batch each:        %.2f us per step   (median), %.2f (min)\n", t_us[t_us.size() / 2], t_us[0]);
