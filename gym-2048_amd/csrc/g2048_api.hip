@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <new>
 
 namespace {
@@ -357,6 +358,8 @@ int g2048_move(g2048_engine *e, const void *actions, int32_t action_dtype, int t
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (action_dtype < G2048_ACT_U8 || action_dtype > G2048_ACT_I64)
         return fail(G2048_ERR_INVALID, "g2048_move needs an action buffer (dtype %d)", action_dtype);
+    if ((reinterpret_cast<uintptr_t>(actions) & (action_size(action_dtype) - 1)) || (reinterpret_cast<uintptr_t>(score_out) & 3u))
+        return fail(G2048_ERR_INVALID, "misaligned buffer: actions need their element size, score_out 4 bytes");
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(g2048::launch_move(e->st.boards, static_cast<uint32_t>(e->n), actions, action_dtype, trial != 0,
                                  score_out, legal_out, static_cast<hipStream_t>(stream)));
@@ -468,6 +471,8 @@ int g2048_get_boards(const g2048_engine *ce, uint8_t *buf, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t n = static_cast<uint32_t>(e->n);
     if (is_device_ptr(buf)) {
+        if (reinterpret_cast<uintptr_t>(buf) & 15u)
+            return fail(G2048_ERR_INVALID, "device board buffers must be 16-byte aligned");
         G2048_HIP(g2048::launch_export_boards(e->st.boards, n, reinterpret_cast<uint4 *>(buf), s));
         return G2048_OK; // device destination: ready in stream order
     }
@@ -509,6 +514,8 @@ int g2048_get_scores(const g2048_engine *ce, int32_t *buf, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t n = static_cast<uint32_t>(e->n);
     if (is_device_ptr(buf)) {
+        if (reinterpret_cast<uintptr_t>(buf) & 3u)
+            return fail(G2048_ERR_INVALID, "device score buffers must be 4-byte aligned");
         G2048_HIP(g2048::launch_export_scores(e->st.boards, n, buf, s));
         return G2048_OK; // device destination: ready in stream order
     }
@@ -535,6 +542,8 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
         if (int rc = copy_in(e, e->scratch, buf, e->n * 4, stream))
             return rc;
         src = static_cast<const int32_t *>(e->scratch);
+    } else if (reinterpret_cast<uintptr_t>(buf) & 3u) {
+        return fail(G2048_ERR_INVALID, "device score buffers must be 4-byte aligned");
     }
     G2048_HIP(g2048::launch_import_scores(e->st.boards, n, src, s));
     if (src == e->scratch)
@@ -551,6 +560,8 @@ int g2048_get_last_scores(const g2048_engine *ce, int32_t *buf, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t n = static_cast<uint32_t>(e->n);
     if (is_device_ptr(buf)) {
+        if (reinterpret_cast<uintptr_t>(buf) & 3u)
+            return fail(G2048_ERR_INVALID, "device score buffers must be 4-byte aligned");
         G2048_HIP(g2048::launch_export_last_scores(e->st, n, buf, s));
         return G2048_OK; // device destination: ready in stream order
     }
@@ -749,9 +760,11 @@ struct Rccl {
 };
 
 Rccl g_rccl;
+std::mutex g_rccl_mutex;
 
 int load_rccl()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle)
         return G2048_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};

@@ -216,6 +216,14 @@ def test_misaligned_buffers_are_refused(torch_cuda):
     io.terminal_boards, io.actions, io.action_dtype = None, buf.data_ptr() + 4, _lib.ACT_I64
     assert e._lib.g2048_step(e._h, C.byref(io), 1, None) == -1
     assert e.clock == 0                                 # nothing was stepped
+    # device-side views of boards / scores use natural-width stores as well
+    lib = e._lib
+    assert lib.g2048_get_boards(e._h, C.c_void_p(buf.data_ptr() + 8), None) == -1 and b"aligned" in lib.g2048_last_error()
+    assert lib.g2048_set_boards(e._h, C.c_void_p(buf.data_ptr() + 8), None) == -1
+    for fn in (lib.g2048_get_scores, lib.g2048_set_scores, lib.g2048_get_last_scores):
+        assert fn(e._h, C.c_void_p(buf.data_ptr() + 2), None) == -1 and b"aligned" in lib.g2048_last_error()
+    assert lib.g2048_move(e._h, C.c_void_p(buf.data_ptr() + 4), _lib.ACT_I64, 1, None, None, None) == -1
+    assert lib.g2048_move(e._h, C.c_void_p(buf.data_ptr()), _lib.ACT_U8, 1, C.c_void_p(buf.data_ptr() + 2), None, None) == -1
 
 
 @pytest.mark.parametrize("args", [("5000", "40", "42", "0"), ("65536", "24", "7", str((1 << 32) - 65536))])
