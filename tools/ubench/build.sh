@@ -10,5 +10,5 @@ for f in g2048_device.h g2048_kernels.h g2048_kernels.hip g2048_pcg64.h; do
 done
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 for t in "$@"; do
-    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -o $t $t.hip
+    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 -o $t $t.hip   # same flags as the product build
 done

@@ -188,6 +188,47 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     }
 }
 
+// ---- the product kernel body with FLAT kernel arguments, so that the first 16 dwords can be preloaded into
+//      SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count=16): no s_load + wait before the
+//      board load can be addressed
+__global__ void __launch_bounds__(256) kern_flat(uint4 *boards, const void *actions, float *reward, uint8_t *terminated,
+                                                 uint4 *last_record, unsigned long long *ep_counters, uint32_t t_lo,
+                                                 uint32_t seed_lo, uint32_t seed_hi, uint32_t board_offset, uint32_t t_hi,
+                                                 float illegal_reward, uint32_t max_exp, uint32_t auto_reset, uint32_t n)
+{
+    using namespace g2048;
+    __shared__ WaveTables s_tables[4];
+    StepArgs p{};
+    p.st.boards = boards; p.st.last_record = last_record; p.st.ep_counters = ep_counters;
+    p.actions = actions; p.reward = reward; p.terminated = terminated;
+    p.n = n; p.board_offset = board_offset; p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.t_lo = t_lo; p.t_hi = t_hi;
+    p.illegal_reward = illegal_reward; p.max_exp = max_exp; p.auto_reset = auto_reset;
+    const uint32_t i_raw = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = i_raw;
+    Board rec = load_board_nt(p.st.boards, i);
+    const uint2 tables_piece = load_tables_piece();
+    const EpisodeCounters counters = load_episode_counters(p, i_raw);
+    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+    const uint32_t action = load_action<1>(p.actions, i, w.w[3]);
+    const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
+    const StepOut o = play_record(rec, action, w, p.max_exp, tb);
+    uint32_t episodes = 0, illegal_ends = 0;
+    record_episode_ends(p, i, o.terminated, !o.legal, rec, episodes, illegal_ends);
+    if (o.terminated && p.auto_reset != 0)
+        reset_record(rec, o, w, tb);
+    store_board_nt(p.st.boards, i, rec);
+    __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + i);
+    __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
+    flush_episode_counts(counters, episodes, illegal_ends);
+}
+
+static void launch_flat(const g2048::StepArgs &a)
+{
+    hipLaunchKernelGGL(kern_flat, dim3(a.n / 256), dim3(256), 0, 0, a.st.boards, a.actions, a.reward, a.terminated, a.st.last_record,
+                       a.st.ep_counters, a.t_lo, a.seed_lo, a.seed_hi, a.board_offset, a.t_hi, a.illegal_reward, a.max_exp,
+                       a.auto_reset, a.n);
+}
+
 template <int X>
 static void launch_x(const g2048::StepArgs &a)
 {
@@ -265,6 +306,7 @@ int main(int argc, char **argv)
     vs.push_back({"v3  step_kernel<1>, no outputs", [&](uint32_t j) { io2(j); a2.reward = nullptr; a2.terminated = nullptr; (void)g2048::launch_step(a2, 1, 0); }});
 
     vs.push_back({"x   copy of the product kernel (sanity: = v3 <1>)", [&](uint32_t j) { io2(j); launch_x<0>(a2); }});
+    vs.push_back({"f   product body, flat kernel arguments (first 16 dwords preloaded into SGPRs when built with -mllvm -amdgpu-kernarg-preload-count=16)", [&](uint32_t j) { io2(j); launch_flat(a2); }});
     vs.push_back({"x   terminal record stored before the in-place reset (no live copy)", [&](uint32_t j) { io2(j); launch_x<X_TERM_FIRST>(a2); }});
     vs.push_back({"x   actions: 16 lanes load a dword, ds_bpermute", [&](uint32_t j) { io2(j); launch_x<X_ACT_PACKED>(a2); }});
     vs.push_back({"x   terminated: ballot -> 16 lanes store a dword", [&](uint32_t j) { io2(j); launch_x<X_TERM_PACKED>(a2); }});
