@@ -50,6 +50,7 @@ struct g2048_engine {
     size_t slab_bytes = 0;
     g2048::DeviceState st{};
     g2048::StatsOut *stats_dev = nullptr;
+    unsigned long long *stats_partials = nullptr; // stage-1 output of the statistics reduction
     void *scratch = nullptr; // staging for host-side get/set of boards and scores (16 B per board), lazily
 };
 
@@ -169,6 +170,12 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
         delete e;
         return fail(G2048_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err));
     }
+    err = hipMalloc(reinterpret_cast<void **>(&e->stats_partials), g2048::kStatsPartialWords * sizeof(unsigned long long));
+    if (err != hipSuccess) {
+        (void)hipFree(e->slab);
+        delete e;
+        return fail(G2048_ERR_NOMEM, "hipMalloc of the statistics scratch failed: %s", hipGetErrorString(err));
+    }
     char *base = static_cast<char *>(e->slab);
     e->st.boards = reinterpret_cast<uint4 *>(base + off_boards);
     e->st.last_record = reinterpret_cast<uint4 *>(base + off_last_record);
@@ -189,6 +196,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipFree(e->st.rng);
         if (e->scratch)
             (void)hipFree(e->scratch);
+        if (e->stats_partials)
+            (void)hipFree(e->stats_partials);
         err = hipFree(e->slab);
     }
     delete e;
@@ -580,7 +589,7 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_dev, s));
+    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, e->stats_dev, s));
     g2048::StatsOut h{};
     G2048_HIP(hipMemcpyAsync(&h, e->stats_dev, sizeof h, hipMemcpyDeviceToHost, s));
     G2048_HIP(hipStreamSynchronize(s));
@@ -603,7 +612,7 @@ int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, vo
     if (!is_device_ptr(device_out))
         return fail(G2048_ERR_INVALID, "g2048_episode_stats_async needs a DEVICE buffer (use g2048_episode_stats for a host struct)");
     G2048_HIP(hipSetDevice(e->device));
-    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), reinterpret_cast<g2048::StatsOut *>(device_out),
+    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, reinterpret_cast<g2048::StatsOut *>(device_out),
                                   static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }

@@ -15,7 +15,7 @@ struct DeviceState {
     uint4 *last_record; // [n] record a board's most recent episode ENDED on (all-zero: none yet); its score is
                         //     that episode's return.  Written only by lanes whose episode ended.
     unsigned long long *ep_counters; // two per 64 boards: {finished episodes, of which ended on an illegal move},
-                                     // bumped with 64-bit atomics by ONE lane of a wavefront that finished episodes
+                                     // updated by ONE lane of a wavefront that finished episodes (old values via the scalar cache)
     uint64_t *rng;      // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
     // numpy-RNG mode only (same allocation, behind the planes): the boards whose episode ended in the current step,
     // one list of up to 64 local board indices per wavefront of the step launch + its length.  The step kernel
@@ -78,7 +78,10 @@ hipError_t launch_fill_actions(uint8_t *out, uint32_t n, uint32_t board_offset, 
 hipError_t launch_onehot(const uint4 *boards, uint32_t n, void *out, int obs_dtype, hipStream_t s);
 hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const uint8_t *actions, uint32_t n,
                           uint4 *boards_out, uint4 *next_out, uint8_t *actions_out, hipStream_t s);
-hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hipStream_t s);
+// partials: kStatsPartialWords uint64 of device scratch (stage 1 -> stage 2; field-major, one column per block)
+constexpr uint32_t kStatsBlocks = 2048;
+constexpr uint32_t kStatsPartialWords = (6 + 32) * kStatsBlocks;
+hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, hipStream_t s);
 // record <-> plain views (cells uint8[n][16], scores int32[n]); device pointers
 hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s);
 hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s);

@@ -784,39 +784,66 @@ __global__ void __launch_bounds__(kBlock) canonicalize_kernel(uint4 *boards, uin
 // Reduce to one StatsOut: the episode counters, the returns of the boards' most recent finished
 // episodes (score of last_record: count / sum / max), the highest tile on any board and the histogram
 // of the boards' highest tiles (what ppo_train.py:77-81 tallies per finished episode, here for the
-// live boards).  Block-level tree in LDS first, then ONE set of atomics per block (a single hot word
-// serialises at ~88 atomics/us on this chip, so per-wave atomics to one address would take hundreds of us).
+// live boards).  Two stages and NO global atomics: a single hot cache line serialises at ~88 atomics/us on
+// this chip (a one-stage version spent 55 us at 2^20 boards in its ~5 000 final atomics).
+//   stage 1: every block reduces its grid-stride share (registers, then a tree in LDS) to kStatsFields
+//            numbers, stored field-major: partials[f * kStatsBlocks + block].  The histogram is counted by
+//            per-wave ballots (the counts are wave-uniform: they live in SGPRs);
+//   stage 2: kStatsFields blocks, block f reduces field f over the partials (coalesced reads, tree in LDS).
+// Cross-lane shuffles are avoided on purpose: a 64-bit __shfl_xor chain costs ~100 cycles per step and the
+// reductions here are latency-, not throughput-bound.
+constexpr int kStatsFields = 6 + 32; // episodes, illegal_ends, last_count, last_score_sum, last_score_max, max_exp, hist[32]
+static_assert(kStatsFields * kStatsBlocks == kStatsPartialWords, "partials buffer size");
+
 __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
-                                                       StatsOut *out)
+                                                       unsigned long long *partials)
 {
     __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock], s_cnt[kBlock];
-    __shared__ int s_max[kBlock], s_exp[kBlock];
+    __shared__ unsigned int s_max[kBlock], s_exp[kBlock];
     __shared__ unsigned int s_hist[32];
     unsigned long long episodes = 0, illegal = 0, score_sum = 0, count = 0;
-    int max_score = 0, max_exp = 0;
-    const uint32_t tid = threadIdx.x;
+    unsigned int max_score = 0, max_exp = 0;
+    uint32_t hist[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        hist[b] = 0u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < 32u)
         s_hist[tid] = 0u;
     __syncthreads();
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t wv = blockIdx.x * kBlock + tid; wv < n_waves; wv += stride) {
-        episodes += st.ep_counters[2u * wv];
-        illegal += st.ep_counters[2u * wv + 1u];
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(st.ep_counters + 2u * wv);
+        episodes += c.x;
+        illegal += c.y;
     }
-    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += stride) {
-        const int h = static_cast<int>(highest(record_cells(load_board(st.boards, i))));
-        max_exp = max(max_exp, h);
-        atomicAdd(&s_hist[h & 31], 1u);
-        const Board last = load_board(st.last_record, i);
-        if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
-            const int sc = static_cast<int>(record_score(last));
-            count += 1;
-            score_sum += static_cast<unsigned long long>(sc);
-            max_score = max(max_score, sc);
+    // whole wavefronts iterate together (the ballots need every lane's vote): lanes past the end vote "none"
+    for (uint64_t base = blockIdx.x * kBlock + tid - lane; base < n; base += stride) { // 64-bit: n may be near 2^32
+        const uint64_t i = base + lane;
+        uint32_t h = 0xffu;
+        if (i < n) {
+            const Board last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
+            h = highest(record_cells(load_board_nt(st.boards, static_cast<uint32_t>(i))));
+            max_exp = max(max_exp, h);
+            if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
+                const unsigned int sc = record_score(last);
+                count += 1;
+                score_sum += sc;
+                max_score = max(max_score, sc);
+            }
         }
+#pragma unroll
+        for (uint32_t b = 0; b < 32u; ++b)
+            hist[b] += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(h == b)));
     }
     s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_cnt[tid] = count;
     s_max[tid] = max_score; s_exp[tid] = max_exp;
+    if (lane == 0u) {
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            if (hist[b] != 0u)
+                atomicAdd(&s_hist[b], hist[b]);
+    }
     __syncthreads();
     for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
         if (tid < off) {
@@ -829,16 +856,52 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
         }
         __syncthreads();
     }
+    unsigned long long *mine = partials + blockIdx.x;
     if (tid == 0) {
-        atomicAdd(&out->episodes, s_ep[0]);
-        atomicAdd(&out->illegal_ends, s_ill[0]);
-        atomicAdd(&out->last_count, s_cnt[0]);
-        atomicAdd(&out->last_score_sum, s_sum[0]);
-        atomicMax(&out->last_score_max, s_max[0]);
-        atomicMax(&out->max_exp, static_cast<unsigned int>(s_exp[0]));
+        mine[0 * kStatsBlocks] = s_ep[0];
+        mine[1 * kStatsBlocks] = s_ill[0];
+        mine[2 * kStatsBlocks] = s_cnt[0];
+        mine[3 * kStatsBlocks] = s_sum[0];
+        mine[4 * kStatsBlocks] = s_max[0];
+        mine[5 * kStatsBlocks] = s_exp[0];
     }
-    if (tid < 32u && s_hist[tid] != 0u)
-        atomicAdd(&out->highest_hist[tid], s_hist[tid]);
+    if (tid < 32u)
+        mine[(6u + tid) * kStatsBlocks] = s_hist[tid];
+}
+
+// block f: field f of every partial -> the matching member of *out (fields 4 and 5 are maxima, the rest sums)
+__global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long long *partials, uint32_t n_partials,
+                                                             StatsOut *out)
+{
+    __shared__ unsigned long long s_v[kBlock];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const bool is_max = f == 4u || f == 5u;
+    unsigned long long v = 0;
+    for (uint32_t q = tid; q < n_partials; q += kBlock) {
+        const unsigned long long x = partials[f * kStatsBlocks + q];
+        v = is_max ? (x > v ? x : v) : v + x;
+    }
+    s_v[tid] = v;
+    __syncthreads();
+    for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+            const unsigned long long a = s_v[tid], b = s_v[tid + off];
+            s_v[tid] = is_max ? (b > a ? b : a) : a + b;
+        }
+        __syncthreads();
+    }
+    if (tid != 0)
+        return;
+    v = s_v[0];
+    switch (f) {
+    case 0: out->episodes = v; break;
+    case 1: out->illegal_ends = v; break;
+    case 2: out->last_count = v; break;
+    case 3: out->last_score_sum = v; break;
+    case 4: out->last_score_max = static_cast<int>(v); break;
+    case 5: out->max_exp = static_cast<unsigned int>(v); break;
+    default: out->highest_hist[f - 6u] = static_cast<unsigned int>(v); break;
+    }
 }
 
 // -------------------------------------------------------------------------------- launchers
@@ -1028,15 +1091,15 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
     return hipGetLastError();
 }
 
-hipError_t launch_stats(const DeviceState &st, uint32_t n, StatsOut *dev_out, hipStream_t s)
+hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, hipStream_t s)
 {
-    hipError_t err = hipMemsetAsync(dev_out, 0, sizeof(StatsOut), s);
-    if (err != hipSuccess || n == 0)
-        return err;
     uint32_t blocks = grid_for(n).x;
-    if (blocks > 512u)
-        blocks = 512u;
-    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, dev_out);
+    if (blocks > kStatsBlocks)
+        blocks = kStatsBlocks;
+    if (blocks == 0)
+        blocks = 1; // n == 0: one block writes an all-zero partial
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
+    hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out);
     return hipGetLastError();
 }
 
