@@ -298,7 +298,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_provenance": traffic_prov,
-                     "kernel": "g2048::step_kernel<1, true>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                     "kernel": "g2048::step_kernel<1, true, true>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us,
                      "note": (f"the {working_set_mib:.0f} MiB of board records touched per launch sit in the 256 MiB "
                               "Infinity Cache at this batch size, so this is a cache-resident figure; "

@@ -198,7 +198,9 @@ struct StepTail {
     uint32_t auto_reset;
 };
 
-template <int ACT, bool FULL>
+// STD: the standard set of outputs -- reward and terminated present, no illegal / highest / terminal_boards -- so
+// none of the five "is this output wanted" branches exists (a taken scalar branch costs a wavefront ~20 cycles).
+template <int ACT, bool FULL, bool STD>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
             uint32_t seed_hi, uint32_t t_lo, uint32_t t_hi, uint32_t n, float *reward, const StepTail tail)
@@ -211,9 +213,9 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
     p.actions = actions;
     p.reward = reward;
     p.terminated = tail.terminated;
-    p.illegal = tail.illegal;
-    p.highest = tail.highest;
-    p.terminal_boards = tail.terminal_boards;
+    p.illegal = STD ? nullptr : tail.illegal;
+    p.highest = STD ? nullptr : tail.highest;
+    p.terminal_boards = STD ? nullptr : tail.terminal_boards;
     p.n = n;
     p.board_offset = board_offset;
     p.seed_lo = seed_lo;
@@ -249,9 +251,9 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
 
     if (valid) {
         store_board_nt(p.st.boards, i, rec);
-        if (p.reward)                                              // :90 / :95
+        if (STD || p.reward)                                       // :90 / :95
             __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + i);
-        if (p.terminated)
+        if (STD || p.terminated)
             __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
         if (p.illegal)
             __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + i);
@@ -924,8 +926,15 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     const StepTail tail{a.terminated, a.st.last_record, a.illegal, a.highest, a.terminal_boards, a.illegal_reward, a.max_exp,
                         a.auto_reset};
 #define G2048_STEP(ACT, FULL)                                                                                           \
-    hipLaunchKernelGGL((step_kernel<ACT, FULL>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters, a.board_offset,     \
-                       a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail)
+    do {                                                                                                                \
+        if (standard)                                                                                                   \
+            hipLaunchKernelGGL((step_kernel<ACT, FULL, true>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,      \
+                               a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail);                \
+        else                                                                                                            \
+            hipLaunchKernelGGL((step_kernel<ACT, FULL, false>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,     \
+                               a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail);                \
+    } while (0)
+    const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards;
     switch (action_dtype * 2 + (full ? 1 : 0)) {
     case 0: G2048_STEP(0, false); break;
     case 1: G2048_STEP(0, true); break;

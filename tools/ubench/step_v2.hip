@@ -25,7 +25,7 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
        X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
-       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144 };
+       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576 };
 
 template <class T> __device__ __forceinline__ T *off32(T *base, uint32_t i)
 {
@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     if (X & X_OFF32) {
         const u32x4 v = __builtin_nontemporal_load(off32(reinterpret_cast<const u32x4 *>(p.st.boards), i));
         rec = Board{{v.x, v.y, v.z, v.w}};
-    } else
+    } else if (X & X_REC_PLAIN)
+        rec = load_board(p.st.boards, i);
+    else
         rec = load_board_nt(p.st.boards, i);
     const uint2 tables_piece = load_tables_piece();
     // lanes 0,1 of the block touch the NEXT step's 256 action bytes of this block (one dword per 128-byte
@@ -108,14 +110,21 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
         __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, off32(p.reward, i));
         __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), off32(p.terminated, i));
     } else if (valid) {
-        store_board_nt(p.st.boards, i, rec);
+        if (X & X_REC_PLAIN)
+            store_board(p.st.boards, i, rec);
+        else
+            store_board_nt(p.st.boards, i, rec);
+        if (X & X_OUT_PLAIN) {
+            p.reward[i] = o.legal ? static_cast<float>(o.gain) : p.illegal_reward;
+            p.terminated[i] = static_cast<uint8_t>(o.terminated ? 1 : 0);
+        } else
         if (!(X & X_NO_REWARD)) {
             if (X & X_REWARD_U16)
                 __builtin_nontemporal_store(static_cast<uint16_t>(o.gain), reinterpret_cast<uint16_t *>(p.reward) + i);
             else
                 __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + i);
         }
-        if (!(X & (X_NO_TERM | X_TERM_PACKED)))
+        if (!(X & (X_NO_TERM | X_TERM_PACKED | X_OUT_PLAIN)))
             __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
     }
     if (X & X_TERM_PACKED) {
@@ -307,6 +316,9 @@ int main(int argc, char **argv)
 
     vs.push_back({"x   copy of the product kernel (sanity: = v3 <1>)", [&](uint32_t j) { io2(j); launch_x<0>(a2); }});
     vs.push_back({"f   product body, flat kernel arguments (first 16 dwords preloaded into SGPRs when built with -mllvm -amdgpu-kernarg-preload-count=16)", [&](uint32_t j) { io2(j); launch_flat(a2); }});
+    vs.push_back({"x   records with plain (cacheable) loads/stores, outputs nt", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN>(a2); }});
+    vs.push_back({"x   records nt, outputs plain", [&](uint32_t j) { io2(j); launch_x<X_OUT_PLAIN>(a2); }});
+    vs.push_back({"x   everything plain", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN | X_OUT_PLAIN>(a2); }});
     vs.push_back({"x   terminal record stored before the in-place reset (no live copy)", [&](uint32_t j) { io2(j); launch_x<X_TERM_FIRST>(a2); }});
     vs.push_back({"x   actions: 16 lanes load a dword, ds_bpermute", [&](uint32_t j) { io2(j); launch_x<X_ACT_PACKED>(a2); }});
     vs.push_back({"x   terminated: ballot -> 16 lanes store a dword", [&](uint32_t j) { io2(j); launch_x<X_TERM_PACKED>(a2); }});
