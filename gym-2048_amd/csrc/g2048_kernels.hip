@@ -198,8 +198,8 @@ struct StepTail {
     uint32_t auto_reset;
 };
 
-// STD: the standard set of outputs -- reward and terminated present, no illegal / highest / terminal_boards -- so
-// none of the five "is this output wanted" branches exists (a taken scalar branch costs a wavefront ~20 cycles).
+// STD: the standard configuration -- reward and terminated present, no illegal / highest / terminal_boards, no
+// max_tile -- so none of the "is this wanted" branches exists (a taken scalar branch costs a wavefront ~20 cycles).
 template <int ACT, bool FULL, bool STD>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
@@ -238,7 +238,7 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
     const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
 
-    const StepOut o = play_record(rec, action, w, p.max_exp, tb);
+    const StepOut o = play_record(rec, action, w, STD ? 0u : p.max_exp, tb);
 
     // episode ends first: the terminal record goes out before the reset overwrites it in place
     uint32_t episodes = 0, illegal_ends = 0;
@@ -934,7 +934,7 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
             hipLaunchKernelGGL((step_kernel<ACT, FULL, false>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,     \
                                a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail);                \
     } while (0)
-    const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards;
+    const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0;
     switch (action_dtype * 2 + (full ? 1 : 0)) {
     case 0: G2048_STEP(0, false); break;
     case 1: G2048_STEP(0, true); break;
