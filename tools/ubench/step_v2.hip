@@ -200,19 +200,20 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
 // ---- the product kernel body with FLAT kernel arguments, so that the first 16 dwords can be preloaded into
 //      SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count=16): no s_load + wait before the
 //      board load can be addressed
-__global__ void __launch_bounds__(256) kern_flat(uint4 *boards, const void *actions, float *reward, uint8_t *terminated,
+template <int BS>
+__global__ void __launch_bounds__(BS) kern_flat(uint4 *boards, const void *actions, float *reward, uint8_t *terminated,
                                                  uint4 *last_record, unsigned long long *ep_counters, uint32_t t_lo,
                                                  uint32_t seed_lo, uint32_t seed_hi, uint32_t board_offset, uint32_t t_hi,
                                                  float illegal_reward, uint32_t max_exp, uint32_t auto_reset, uint32_t n)
 {
     using namespace g2048;
-    __shared__ WaveTables s_tables[4];
+    __shared__ WaveTables s_tables[BS / 64];
     StepArgs p{};
     p.st.boards = boards; p.st.last_record = last_record; p.st.ep_counters = ep_counters;
     p.actions = actions; p.reward = reward; p.terminated = terminated;
     p.n = n; p.board_offset = board_offset; p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.t_lo = t_lo; p.t_hi = t_hi;
     p.illegal_reward = illegal_reward; p.max_exp = max_exp; p.auto_reset = auto_reset;
-    const uint32_t i_raw = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i_raw = blockIdx.x * BS + threadIdx.x;
     const uint32_t i = i_raw;
     Board rec = load_board_nt(p.st.boards, i);
     const uint2 tables_piece = load_tables_piece();
@@ -231,9 +232,10 @@ __global__ void __launch_bounds__(256) kern_flat(uint4 *boards, const void *acti
     flush_episode_counts(counters, episodes, illegal_ends);
 }
 
+template <int BS>
 static void launch_flat(const g2048::StepArgs &a)
 {
-    hipLaunchKernelGGL(kern_flat, dim3(a.n / 256), dim3(256), 0, 0, a.st.boards, a.actions, a.reward, a.terminated, a.st.last_record,
+    hipLaunchKernelGGL(kern_flat<BS>, dim3(a.n / BS), dim3(BS), 0, 0, a.st.boards, a.actions, a.reward, a.terminated, a.st.last_record,
                        a.st.ep_counters, a.t_lo, a.seed_lo, a.seed_hi, a.board_offset, a.t_hi, a.illegal_reward, a.max_exp,
                        a.auto_reset, a.n);
 }
@@ -315,7 +317,11 @@ int main(int argc, char **argv)
     vs.push_back({"v3  step_kernel<1>, no outputs", [&](uint32_t j) { io2(j); a2.reward = nullptr; a2.terminated = nullptr; (void)g2048::launch_step(a2, 1, 0); }});
 
     vs.push_back({"x   copy of the product kernel (sanity: = v3 <1>)", [&](uint32_t j) { io2(j); launch_x<0>(a2); }});
-    vs.push_back({"f   product body, flat kernel arguments (first 16 dwords preloaded into SGPRs when built with -mllvm -amdgpu-kernarg-preload-count=16)", [&](uint32_t j) { io2(j); launch_flat(a2); }});
+    vs.push_back({"f   product body, flat kernel arguments (first 16 dwords preloaded into SGPRs when built with -mllvm -amdgpu-kernarg-preload-count=16)", [&](uint32_t j) { io2(j); launch_flat<256>(a2); }});
+    vs.push_back({"f   the same, 64-lane blocks", [&](uint32_t j) { io2(j); launch_flat<64>(a2); }});
+    vs.push_back({"f   the same, 128-lane blocks", [&](uint32_t j) { io2(j); launch_flat<128>(a2); }});
+    vs.push_back({"f   the same, 512-lane blocks", [&](uint32_t j) { io2(j); launch_flat<512>(a2); }});
+    vs.push_back({"f   the same, 1024-lane blocks", [&](uint32_t j) { io2(j); launch_flat<1024>(a2); }});
     vs.push_back({"x   records with plain (cacheable) loads/stores, outputs nt", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN>(a2); }});
     vs.push_back({"x   records nt, outputs plain", [&](uint32_t j) { io2(j); launch_x<X_OUT_PLAIN>(a2); }});
     vs.push_back({"x   everything plain", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN | X_OUT_PLAIN>(a2); }});
