@@ -166,6 +166,37 @@ def test_random_rollout_vs_oracle(torch_cuda, n, seed, offset, irw, max_tile, au
     assert np.array_equal((raw_last & 0x1F)[had], o.terminal_boards[had]) and not raw_last[~had].any()
 
 
+@pytest.mark.parametrize("n,dtype_name,irw,auto_reset", [
+    (4096, "uint8", -2.0, True),       # whole blocks: the FULL + standard-configuration kernel
+    (4096, "int64", 0.0, False),
+    (1000, "int32", -1.0, True),       # ragged
+    (63, "uint8", 0.0, True),
+    (65536, "int64", -0.5, True),
+])
+def test_standard_configuration_kernel_vs_oracle(torch_cuda, n, dtype_name, irw, auto_reset):
+    """step(want_info=False) -- reward + terminated only, no max_tile -- runs step_kernel's specialisation without
+    the optional-output branches; the oracle decides."""
+    from oracle import OracleBatch
+    from oracle.cpu_ref import random_actions_np
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    seed, off = 77, 4242
+    eng = Batched2048(n, seed=seed, board_offset=off, illegal_move_reward=irw)
+    ora = OracleBatch(n, seed, off, threads=0)
+    ora.illegal_move_reward = irw
+    eng.reset()
+    ora.reset()
+    for s in range(40):
+        a = random_actions_np(seed + 1, 1 + s, off, n)          # any action sequence will do
+        r, t = eng.step(torch.as_tensor(a).to(getattr(torch, dtype_name)).to(eng.device), auto_reset=auto_reset,
+                        want_info=False)
+        ora.step(a, auto_reset=auto_reset)
+        assert np.array_equal(r.cpu().numpy(), ora.reward) and np.array_equal(t.cpu().numpy(), ora.terminated), s
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards)
+    assert np.array_equal(eng.get_scores(), ora.score) and np.array_equal(eng.get_last_scores(), ora.last_score)
+    assert eng.episode_stats()["episodes"] == int(ora.ep_count.sum())
+
+
 def test_action_dtypes_and_generated_actions(torch_cuda):
     """u8 / i32 / i64 action buffers and the synthetic policy give identical trajectories; the
     device-generated action tensor equals the CPU regeneration."""
