@@ -38,12 +38,16 @@ def once(mode):
     if mode == "spin":
         while not ev1.query():
             pass
+    elif mode == "stream":
+        torch.cuda.current_stream().synchronize()
+    elif mode == "event":
+        ev1.synchronize()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     return (t_enq - t0) * 1e6, (t1 - t0) * 1e6, ev0.elapsed_time(ev1) * 1e3
 
 
-for mode in ("sync", "spin", "sync", "spin"):
+for mode in ("sync", "spin", "stream", "event", "sync", "stream", "event"):
     rows = sorted(once(mode) for _ in range(30))
     med = rows[len(rows) // 2]
     enq = sorted(r[0] for r in rows)[15]
