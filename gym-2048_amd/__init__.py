@@ -8,6 +8,7 @@ from ._lib import G2048Error, LIB_PATH  # noqa: F401
 from .env import Game2048Env, IllegalMove, stack  # noqa: F401
 from .vec_env import Vec2048  # noqa: F401
 from .sharding import Shard, shard_range, weak_shard, allgather_returns  # noqa: F401
+from .evaluate import evaluate_model, report_evaluation_results  # noqa: F401
 
 __version__ = "0.1.0"
 ENV_ID = "2048-v0"  # the reference's registration id (env/__init__.py:3-6)

@@ -12,10 +12,13 @@ I64x16 = C.c_int64 * 16
 
 
 class OracleEngine:
-    def __init__(self, n_envs, seed=0, board_offset=0):
+    def __init__(self, n_envs, seed=0, board_offset=0, rng="philox"):
         self.ob = OracleBatch(n_envs, seed, board_offset)
         self.n_envs = n_envs
         self.max_tile = None
+        self.rng_mode = rng
+        if rng == "numpy":
+            self.ob.seed_numpy(int(seed))
 
     # configuration
     def set_illegal_move_reward(self, r):
@@ -26,17 +29,32 @@ class OracleEngine:
         self.ob.max_exp = 0 if max_tile is None else int(max_tile).bit_length() - 1
 
     def seed(self, seed):
-        self.ob.seed_(int(seed))
+        if self.rng_mode == "numpy":
+            self.ob.seed_numpy(int(seed))
+        else:
+            self.ob.seed_(int(seed))
+
+    def close(self):
+        pass
 
     # reset / step
     def reset(self, seed=None, first_slot=0, new_transaction=None, mask=None):
         if seed is not None:
             self.seed(seed)
         assert mask is None
-        self.ob.reset(first_slot=first_slot, new_transaction=new_transaction)
+        if self.rng_mode == "numpy":
+            self.ob.reset_numpy()
+        else:
+            self.ob.reset(first_slot=first_slot, new_transaction=new_transaction)
+
+    def observe_onehot(self, dtype=np.float32):
+        return self.ob.onehot().astype(dtype)
 
     def step_numpy(self, actions, auto_reset=True):
-        self.ob.step(np.asarray(actions) & 3, auto_reset=auto_reset)
+        if self.rng_mode == "numpy":
+            self.ob.step_numpy(np.asarray(actions) & 3, auto_reset=auto_reset)
+        else:
+            self.ob.step(np.asarray(actions) & 3, auto_reset=auto_reset)
         o = self.ob
         return dict(reward=o.reward.copy(), terminated=o.terminated.astype(bool), illegal=o.illegal.astype(bool),
                     highest=o.highest.copy(), terminal_boards=o.terminal_boards.reshape(-1, 4, 4).copy(),

@@ -576,12 +576,65 @@ def time_reference(ref, report):
                   f"(1 core, this container)")
 
 
+def eval_policy_weights(rng):
+    """Integer weights of the linear stand-in policy used for the evaluation-loop fixture: scores[a] =
+    sum(W[a] * onehot) + 0.25 * (3 - a).  Integer sums are exact in float32 on any device and the quarter
+    steps break every tie the same way everywhere, so the greedy action never depends on argmax's tie rule."""
+    return rng.integers(-8, 9, size=(4, 16, 4, 4)).astype(np.int32)
+
+
+def gen_eval_table(ref, rng):
+    """The reference's own evaluation loop (train.py:127-165 evaluate_episode, driven as train.py:183-200
+    evaluate_model does: seed = 456 + i, agent_seed = 123 + i, illegal_move_reward = -1) with a small
+    deterministic policy, for epsilon 0 and 0.3; plus the CSV report_evaluation_results writes."""
+    import importlib
+    import tempfile
+    import torch
+    train = importlib.import_module("train")
+    W = eval_policy_weights(rng)
+
+    class IntPolicy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.from_numpy(W.astype(np.float32)), requires_grad=False)
+            self.b = torch.nn.Parameter(torch.tensor([0.75, 0.5, 0.25, 0.0]), requires_grad=False)
+
+        def forward(self, x):                              # x: (B, 16, 4, 4) as model.observation_to_tensor makes it
+            return torch.einsum("bcyx,acyx->ba", x, self.w) + self.b
+
+    model = IntPolicy()
+    episodes = 24
+    out = {"weights": W, "episodes": np.int64(episodes)}
+    for tag, eps in (("eps0", 0.0), ("eps03", 0.3)):
+        env = ref.Game2048Env()
+        env.set_illegal_move_reward(-1.)                   # train.py:184
+        rows = []
+        for i in range(episodes):                          # train.py:187-200
+            total_reward, moves, illegals, highest = train.evaluate_episode(model, env, eps, seed=456 + i,
+                                                                            agent_seed=123 + i)
+            rows.append({"total_reward": total_reward, "highest": highest, "moves": moves, "illegal_moves": illegals})
+        out[f"{tag}_total_reward"] = np.array([r["total_reward"] for r in rows], np.float64)
+        out[f"{tag}_highest"] = np.array([r["highest"] for r in rows], np.int64)
+        out[f"{tag}_moves"] = np.array([r["moves"] for r in rows], np.int64)
+        out[f"{tag}_illegal_moves"] = np.array([r["illegal_moves"] for r in rows], np.int64)
+        results = {"Episodes": rows}
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as d:           # report_evaluation_results writes into the cwd
+            os.chdir(d)
+            try:
+                train.report_evaluation_results(results, label=tag)
+                out[f"{tag}_csv"] = np.frombuffer(open(f"scores_{tag}.csv", "rb").read(), np.uint8)
+            finally:
+                os.chdir(cwd)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--validate-steps", type=int, default=1_000_000)
     ap.add_argument("--only-numpy", action="store_true", help="only (re)generate the numpy-RNG trajectories")
     ap.add_argument("--only-data", action="store_true", help="only (re)generate the training_data fixtures")
-    ap.add_argument("--only-round2", action="store_true", help="only (re)generate render_ansi / canonical_table")
+    ap.add_argument("--only-round2", action="store_true", help="only (re)generate the fixtures added in round 2")
     args = ap.parse_args()
     ref = import_reference()
     rng = np.random.default_rng(20480)
@@ -602,6 +655,7 @@ def main():
         save("rewards_table.npz", gen_rewards_table(ref, np.random.default_rng(9)))
         save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
         save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
+        save("eval_table.npz", gen_eval_table(ref, np.random.default_rng(10)))
         print("\n".join(report))
         return
     save("training_data_fixture.npz", gen_training_data_fixtures(report))
@@ -628,6 +682,7 @@ def main():
     save("rewards_table.npz", gen_rewards_table(ref, np.random.default_rng(9)))
     save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
     save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
+    save("eval_table.npz", gen_eval_table(ref, np.random.default_rng(10)))
     validate(ref, args.validate_steps, report)
     time_reference(ref, report)
     with open(os.path.join(HERE, "VALIDATION.txt"), "w") as f:

@@ -562,3 +562,21 @@ def test_seeding_helpers_round_trip():
     for s, g in zip([3, 4, 2 ** 35], gens):
         want = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
         assert g.random() == want.random() and g.integers(0, 100) == want.integers(0, 100)
+
+
+@pytest.mark.parametrize("tag,eps", [("eps0", 0.0), ("eps03", 0.3)])
+def test_evaluate_model_on_the_gpu_equals_the_reference_evaluation_loop(torch_cuda, tag, eps, tmp_path):
+    """gym2048_amd.evaluate.evaluate_model with the HIP engine (numpy-RNG mode, 24 episodes in lockstep) == what
+    train.py:127-229 computed on the unmodified reference with the same policy (tests/golden/eval_table.npz)."""
+    from test_host_logic import eval_fixture_policy
+    from gym2048_amd.evaluate import evaluate_model, report_evaluation_results
+    g = load_golden("eval_table")
+    n = int(g["episodes"])
+    res = evaluate_model(eval_fixture_policy(g["weights"]), n, eps)
+    rows = res["Episodes"]
+    assert [r["total_reward"] for r in rows] == g[f"{tag}_total_reward"].tolist()
+    assert [r["highest"] for r in rows] == g[f"{tag}_highest"].tolist()
+    assert [r["moves"] for r in rows] == g[f"{tag}_moves"].tolist()
+    assert [r["illegal_moves"] for r in rows] == g[f"{tag}_illegal_moves"].tolist()
+    name = report_evaluation_results(res, label=tag, path=str(tmp_path / f"scores_{tag}.csv"))
+    assert open(name, "rb").read() == bytes(g[f"{tag}_csv"])

@@ -305,3 +305,37 @@ def test_real_gymnasium_and_sb3_accept_the_drop_ins():
     pytest.importorskip("stable_baselines3")
     from stable_baselines3.common.vec_env import VecEnv
     assert isinstance(gym2048_amd.Vec2048(4, engine=OracleEngine(4, 3)), VecEnv)
+
+
+def eval_fixture_policy(weights):
+    """The linear stand-in policy of tests/golden/eval_table.npz (make_golden.eval_policy_weights): exact integer
+    scores + quarter-step tie-breakers, on numpy or torch observations."""
+    w = weights.astype(np.float32)
+    bias = np.array([0.75, 0.5, 0.25, 0.0], np.float32)
+
+    def policy(obs):
+        if isinstance(obs, np.ndarray):
+            return np.einsum("bcyx,acyx->ba", obs.astype(np.float32), w) + bias
+        import torch
+        return torch.einsum("bcyx,acyx->ba", obs.float(), torch.from_numpy(w).to(obs.device)) + torch.from_numpy(bias).to(obs.device)
+    return policy
+
+
+@pytest.mark.parametrize("tag,eps", [("eps0", 0.0), ("eps03", 0.3)])
+def test_evaluate_model_reproduces_the_reference_evaluation_loop(tag, eps, tmp_path):
+    """evaluate.py (host logic) over the oracle in numpy-RNG mode == train.py's evaluate_episode / evaluate_model /
+    report_evaluation_results run on the unmodified reference (fixture made by make_golden.gen_eval_table)."""
+    from gym2048_amd.evaluate import evaluate_model, report_evaluation_results
+    g = load_golden("eval_table")
+    n = int(g["episodes"])
+    res = evaluate_model(eval_fixture_policy(g["weights"]), n, eps, engine=OracleEngine(n, seed=456, rng="numpy"),
+                         obs_dtype=np.float32)
+    rows = res["Episodes"]
+    assert [r["total_reward"] for r in rows] == g[f"{tag}_total_reward"].tolist()
+    assert [r["highest"] for r in rows] == g[f"{tag}_highest"].tolist()
+    assert [r["moves"] for r in rows] == g[f"{tag}_moves"].tolist()
+    assert [r["illegal_moves"] for r in rows] == g[f"{tag}_illegal_moves"].tolist()
+    assert res["Average score"] == sum(g[f"{tag}_total_reward"].tolist()) / n                 # train.py:203
+    assert res["Max score"] == g[f"{tag}_total_reward"].max() and res["Highest tile"] == g[f"{tag}_highest"].max()
+    name = report_evaluation_results(res, label=tag, path=str(tmp_path / f"scores_{tag}.csv"))
+    assert open(name, "rb").read() == bytes(g[f"{tag}_csv"])                                  # train.py:216-229
