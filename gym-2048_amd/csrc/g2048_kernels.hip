@@ -407,9 +407,10 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
 }
 
 // The `if terminated: env.reset()` of numpy-RNG mode (game2048_env.py:102-111) for the boards the step kernel
-// listed: one wavefront serves the lists of kListGroup step wavefronts (63 boards expected under a random
-// policy), one lane per listed board, so the two expensive spawns run with nearly every lane busy.
-constexpr uint32_t kListGroup = 16;
+// listed: one wavefront serves the lists of kListGroup step wavefronts (32 boards expected under a random
+// policy: one trip of the loop below, and twice as many wavefronts in flight as with groups of 16, where 45 % of
+// the groups needed a second, nearly empty trip -- 26 -> 21 us at 2^20 boards), one lane per listed board.
+constexpr uint32_t kListGroup = 8;
 
 __global__ void __launch_bounds__(64) reset_list_numpy_kernel(const StepArgs p, uint32_t n_waves)
 {
