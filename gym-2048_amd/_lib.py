@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class G2048Error(RuntimeError):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "g2048_rollout_random": (C.c_int, [_E, _u32, _S]),
     "g2048_move": (C.c_int, [_E, C.c_void_p, _i32, C.c_int, C.c_void_p, C.c_void_p, _S]),
     "g2048_query": (C.c_int, [_E, C.c_void_p, C.c_void_p, _S]),
+    "g2048_legal_actions": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_add_tile": (C.c_int, [_E, _u32, _S]),
     "g2048_fill_random_actions": (C.c_int, [_E, _u64, _u32, C.c_void_p, _S]),
     "g2048_onehot": (C.c_int, [_E, C.c_void_p, _i32, _S]),

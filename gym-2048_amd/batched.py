@@ -484,6 +484,16 @@ class Batched2048:
         check(self._lib.g2048_query(self._h, end.data_ptr(), hi.data_ptr(), self._stream()))
         return end, hi
 
+    def legal_actions(self, out=None) -> torch.Tensor:
+        """Device ``uint8[n]`` mask, bit ``d`` set = move ``d`` is legal (the four trial moves of
+        game2048_env.py:273-280 in one launch); 0 = the board has no move left."""
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
+        if out.dtype != torch.uint8 or out.shape != (self.n_envs,) or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"out must be a contiguous uint8 [{self.n_envs}] tensor on the engine's device")
+        check(self._lib.g2048_legal_actions(self._h, out.data_ptr(), self._stream()))
+        return out
+
     def isend_numpy(self) -> np.ndarray:
         return self.query()[0].cpu().numpy().astype(bool)
 

@@ -122,7 +122,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 7; }
+int g2048_abi_version(void) { return 8; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -382,6 +382,15 @@ int g2048_query(const g2048_engine *e, uint8_t *isend_out, uint8_t *highest_out,
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(g2048::launch_query(e->st.boards, static_cast<uint32_t>(e->n), e->max_exp, isend_out, highest_out,
                                   static_cast<hipStream_t>(stream)));
+    return G2048_OK;
+}
+
+int g2048_legal_actions(const g2048_engine *e, uint8_t *mask_out, void *stream)
+{
+    if (!e || !mask_out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    G2048_HIP(g2048::launch_legal_mask(e->st.boards, static_cast<uint32_t>(e->n), mask_out, static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
 

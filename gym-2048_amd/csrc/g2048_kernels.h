@@ -67,6 +67,7 @@ hipError_t launch_move(uint4 *boards, uint32_t n, const void *actions, int actio
                        int32_t *score_out, uint8_t *legal_out, hipStream_t s);
 hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8_t *isend_out, uint8_t *highest_out,
                         hipStream_t s);
+hipError_t launch_legal_mask(const uint4 *boards, uint32_t n, uint8_t *mask_out, hipStream_t s);
 hipError_t launch_add_tile(const StepArgs &a, uint32_t slot, hipStream_t s);
 // the same three in numpy-RNG mode (a.st.rng != NULL)
 hipError_t launch_seed_numpy(uint64_t *planes, uint32_t n, uint64_t first_seed, hipStream_t s);

@@ -544,6 +544,26 @@ __global__ void __launch_bounds__(kBlock) query_kernel(const uint4 *boards, uint
         highest_out[i] = static_cast<uint8_t>(highest(bd));
 }
 
+// The four trial moves of isend (game2048_env.py:273-280) as a mask: bit d = move d changes the board.
+__global__ void __launch_bounds__(kBlock) legal_mask_kernel(const uint4 *boards, uint32_t n, uint8_t *mask_out)
+{
+    __shared__ WaveTables s_tables[kBlock / 64];
+    const LdsTables tb = stage_tables(s_tables, load_tables_piece());
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const Board cells = record_cells(load_board(boards, i));
+    uint32_t mask = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 4u; ++d) {
+        Board trial = cells;                                   // trial=True: the board itself is left alone (:224,:236)
+        uint32_t gain;
+        if (move_sel(trial, tb.move_sel(d), gain))
+            mask |= 1u << d;
+    }
+    mask_out[i] = static_cast<uint8_t>(mask);
+}
+
 // Game2048Env.add_tile (game2048_env.py:166-176) from spawn slot `slot` of transaction t.
 __global__ void __launch_bounds__(kBlock) add_tile_kernel(const StepArgs p, uint32_t slot)
 {
@@ -973,6 +993,14 @@ hipError_t launch_query(const uint4 *boards, uint32_t n, uint32_t max_exp, uint8
     if (n == 0)
         return hipSuccess;
     hipLaunchKernelGGL(query_kernel, grid_for(n), dim3(kBlock), 0, s, boards, n, max_exp, isend_out, highest_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_legal_mask(const uint4 *boards, uint32_t n, uint8_t *mask_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(legal_mask_kernel, grid_for(n), dim3(kBlock), 0, s, boards, n, mask_out);
     return hipGetLastError();
 }
 

@@ -156,6 +156,12 @@ int g2048_move(g2048_engine *e, const void *actions, int32_t action_dtype, int t
  * an exponent) for every board; either output may be NULL. */
 int g2048_query(const g2048_engine *e, uint8_t *isend_out, uint8_t *highest_out, void *stream);
 
+/* The four trial moves of Game2048Env.isend (game2048_env.py:273-280: `self.move(direction, trial=True)` for
+ * direction 0..3, catching IllegalMove) for every board, kept as a mask instead of collapsed to one flag:
+ * mask_out uint8[n], bit d set = move d is legal on that board (0 = no move left).  What a legality-aware
+ * policy masks its logits with; one launch instead of four g2048_move(trial) calls.  Boards are not modified. */
+int g2048_legal_actions(const g2048_engine *e, uint8_t *mask_out, void *stream);
+
 /* Game2048Env.add_tile (game2048_env.py:166-176): one spawn from slot `slot` of the current
  * transaction on every board that has an empty cell. */
 int g2048_add_tile(g2048_engine *e, uint32_t slot, void *stream);

@@ -28,13 +28,10 @@ gen = torch.Generator(device=eng.device)
 gen.manual_seed(1)
 t0 = time.time()
 for s in range(steps):
+    mask = eng.legal_actions()                                   # bit d = move d is legal
     choice = torch.full((n,), 3, dtype=torch.uint8, device=eng.device)
-    found = torch.zeros(n, dtype=torch.bool, device=eng.device)
-    for d in (3, 2, 1, 0):
-        _, legal = eng.move(torch.full((n,), d, dtype=torch.uint8, device=eng.device), trial=True)
-        take = legal.bool() & ~found
-        choice = torch.where(take, torch.full_like(choice, d), choice)
-        found |= take
+    for d in (0, 1, 2, 3):                                       # highest legal direction wins: 3, 2, 1, 0
+        choice = torch.where((mask >> d) & 1 == 1, torch.full_like(choice, d), choice)
     rnd = torch.rand(n, device=eng.device, generator=gen) < noise
     rand_a = torch.randint(0, 4, (n,), device=eng.device, generator=gen, dtype=torch.uint8)
     acts = torch.where(rnd, rand_a, choice)

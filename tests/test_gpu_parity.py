@@ -68,6 +68,10 @@ def test_move_table(torch_cuda):
     eng.set_boards(m["boards"])
     end, hi = eng.query()
     assert np.array_equal(end.cpu().numpy(), m["isend"]) and np.array_equal(hi.cpu().numpy(), m["highest"])
+    # the four trial moves of isend (game2048_env.py:273-280) as one mask, against the reference's own legality flags
+    want_mask = (m["legal"].astype(np.uint8) << np.arange(4, dtype=np.uint8)).sum(axis=1).astype(np.uint8)
+    assert np.array_equal(eng.legal_actions().cpu().numpy(), want_mask)
+    assert np.array_equal(eng.get_boards().reshape(n, 16), m["boards"])          # nothing moved
 
 
 def test_shift_exhaustive(torch_cuda):
