@@ -128,7 +128,18 @@ class Vec2048(_vec_env_base()):
         else:
             raise AttributeError(f"cannot set {attr_name} on a batched env")
 
+    def action_masks(self) -> np.ndarray:
+        """bool ``[num_envs, 4]``: which moves are legal right now (the four trial moves of
+        game2048_env.py:273-280 for every env in one launch) -- the method sb3-contrib's MaskablePPO asks a
+        vector env for through ``env_method("action_masks")``."""
+        mask = self.engine.legal_actions()
+        mask = mask.cpu().numpy() if hasattr(mask, "cpu") else np.asarray(mask)
+        return ((mask[:, None] >> np.arange(4, dtype=np.uint8)) & 1).astype(bool)
+
     def env_method(self, method_name, *args, indices=None, **kwargs):
+        if method_name == "action_masks":
+            rows = self.action_masks()
+            return [rows[i] for i in self._indices(indices)]
         if method_name == "set_illegal_move_reward":
             self.set_attr("illegal_move_reward", *args)
         elif method_name == "set_max_tile":

@@ -87,6 +87,12 @@ class OracleEngine:
                 self.ob.boards[i] = [0 if v == 0 else int(v).bit_length() - 1 for v in M]
         return score, legal
 
+    def legal_actions(self):
+        mask = np.zeros(self.n_envs, np.uint8)
+        for d in range(4):
+            mask |= self.move_numpy(np.full(self.n_envs, d), trial=True)[1].astype(np.uint8) << d
+        return mask
+
     def isend_numpy(self):
         mt = 0 if self.max_tile is None else int(self.max_tile)
         return np.array([bool(self.ob.lib.g2048o_isend(self._values(i), mt)) for i in range(self.n_envs)])

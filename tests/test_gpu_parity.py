@@ -375,6 +375,7 @@ def test_vec_env_adapter_matches_oracle_backed_adapter(torch_cuda):
                 assert x["episode"]["r"] == y["episode"]["r"] and x["episode"]["l"] == y["episode"]["l"]
                 assert x["highest"] == y["highest"] and x["illegal_move"] == y["illegal_move"]
                 assert np.array_equal(x["terminal_observation"], y["terminal_observation"])
+        assert np.array_equal(real.action_masks(), fake.action_masks())      # g2048_legal_actions vs the oracle's trial moves
     assert real.render().shape == (280, 280, 3)
 
 

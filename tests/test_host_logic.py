@@ -207,6 +207,15 @@ def test_vec_env_surface_and_infos():
     assert ve.get_attr("illegal_move_reward", indices=[0, 1]) == [-2.0, -2.0]
     assert ve.env_is_wrapped(object) == [False] * n and ve.seed(3)[:2] == [3, 4]
     assert ve.get_images()[0].shape == (280, 280, 3)
+    # action masks (sb3-contrib's MaskablePPO convention): an illegal move really is the reference's IllegalMove
+    masks = ve.action_masks()
+    assert masks.shape == (n, 4) and masks.dtype == bool
+    assert [m.tolist() for m in ve.env_method("action_masks", indices=[1, 5])] == [masks[1].tolist(), masks[5].tolist()]
+    ve.step_async(np.array([int(np.argmin(m)) if not m.all() else 0 for m in masks]))      # an illegal move where one exists
+    _, rewards, dones, infos = ve.step_wait()
+    for i in range(n):
+        if not masks[i].all():
+            assert dones[i] and infos[i]["illegal_move"] and rewards[i] == -2.0
 
 
 def test_vec_env_equals_independent_single_envs():
