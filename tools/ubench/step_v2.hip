@@ -25,7 +25,7 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
        X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
-       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576 };
+       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576, X_CHEAP_RNG = 2097152 };
 
 template <class T> __device__ __forceinline__ T *off32(T *base, uint32_t i)
 {
@@ -82,7 +82,13 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     uint32_t packed_actions = 0;
     if ((X & X_ACT_PACKED) && lane < 16u)
         packed_actions = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p.actions) + (i_raw & ~63u)) + lane);
-    const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
+    Words w;
+    if (X & X_CHEAP_RNG) { // NOT the spawn stream: a two-multiply hash, to see what the Philox block costs
+        const uint32_t h = (p.board_offset + i) * 0x9E3779B1u + p.t_lo * 0x85EBCA77u + p.seed_lo;
+        const uint32_t g = (h ^ (h >> 15)) * 0xC2B2AE3Du;
+        w = Words{{g ^ (g >> 13), g * 0x27D4EB2Fu, h ^ g, h}};
+    } else
+        w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
     uint32_t action;
     if (X & X_NO_ACT)
         action = w.w[3] >> 30;
@@ -322,6 +328,7 @@ int main(int argc, char **argv)
     vs.push_back({"f   the same, 128-lane blocks", [&](uint32_t j) { io2(j); launch_flat<128>(a2); }});
     vs.push_back({"f   the same, 512-lane blocks", [&](uint32_t j) { io2(j); launch_flat<512>(a2); }});
     vs.push_back({"f   the same, 1024-lane blocks", [&](uint32_t j) { io2(j); launch_flat<1024>(a2); }});
+    vs.push_back({"x   a two-multiply hash instead of the Philox block (NOT the stream: cost probe)", [&](uint32_t j) { io2(j); launch_x<X_CHEAP_RNG>(a2); }});
     vs.push_back({"x   records with plain (cacheable) loads/stores, outputs nt", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN>(a2); }});
     vs.push_back({"x   records nt, outputs plain", [&](uint32_t j) { io2(j); launch_x<X_OUT_PLAIN>(a2); }});
     vs.push_back({"x   everything plain", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN | X_OUT_PLAIN>(a2); }});
