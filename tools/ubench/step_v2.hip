@@ -25,7 +25,7 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
        X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
-       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576, X_CHEAP_RNG = 2097152 };
+       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576, X_CHEAP_RNG = 2097152, X_LASTREC_SCORE = 4194304, X_PRE_RESET = 8388608 };
 
 template <class T> __device__ __forceinline__ T *off32(T *base, uint32_t i)
 {
@@ -100,7 +100,20 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
     uint32_t episodes = 0, illegal_ends = 0;
     StepOut o;
-    if (X & X_TERM_FIRST) {
+    if (X & X_PRE_RESET) {
+        // both candidate fresh records (after a legal / an illegal last move) computed from the Philox words BEFORE the
+        // board record is needed -- i.e. while its load is in flight; the reset itself is four selects
+        Board fa = fresh_record_lut(w.w[1], w.w[2], tb), fb = fresh_record_lut(w.w[0], w.w[1], tb);
+        asm volatile("" : "+v"(rec.r[0]), "+v"(rec.r[1]), "+v"(rec.r[2]), "+v"(rec.r[3])
+                     : "v"(fa.r[0]), "v"(fa.r[1]), "v"(fa.r[2]), "v"(fa.r[3]), "v"(fb.r[0]), "v"(fb.r[1]), "v"(fb.r[2]), "v"(fb.r[3]));
+        o = play_record(rec, action, w, p.max_exp, tb);
+        record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+        if (o.terminated && p.auto_reset != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                rec.r[k] = bfi(o.legal_mask, fa.r[k], fb.r[k]);
+        }
+    } else if (X & X_TERM_FIRST) {
         // terminal record stored BEFORE the reset overwrites it in place: no second copy of the record is live
         o = step_record(rec, action, w, p.max_exp, false, tb);
         record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
@@ -143,7 +156,18 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     }
     if ((X & X_PREFETCH) && touched == 0x12345677u)
         p.st.ep_counters[0] = touched; // keeps the touch alive
-    if (X & (X_LASTREC_DENSE | X_LASTREC_4B | X_LASTREC_RING)) {
+    if (X & X_LASTREC_SCORE) {
+        // what a 4-byte "final score" bookkeeping would cost: the potential (and so the score) of the finished
+        // boards computed in-lane, ONE dword stored per finished board
+        const bool fin = o.terminated && valid;
+        const unsigned long long done = __ballot(fin);
+        if (done) {
+            if (fin)
+                reinterpret_cast<uint32_t *>(p.st.last_record)[i] = record_score(o.terminal);
+            episodes += (uint32_t)__popcll(done);
+            illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
+        }
+    } else if (X & (X_LASTREC_DENSE | X_LASTREC_4B | X_LASTREC_RING)) {
         const bool fin = o.terminated && valid;
         const unsigned long long done = __ballot(fin);
         if (done) {
@@ -184,7 +208,7 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
             episodes += (uint32_t)__popcll(done);
             illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
         }
-    } else if (!(X & (X_NO_LASTREC | X_TERM_FIRST)))
+    } else if (!(X & (X_NO_LASTREC | X_TERM_FIRST | X_LASTREC_SCORE | X_PRE_RESET)))
         record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
     if (!(X & (X_NO_COUNT | X_COUNT_RMW))) {
         if (episodes != 0u && lane == 0u) {
@@ -329,6 +353,8 @@ int main(int argc, char **argv)
     vs.push_back({"f   the same, 512-lane blocks", [&](uint32_t j) { io2(j); launch_flat<512>(a2); }});
     vs.push_back({"f   the same, 1024-lane blocks", [&](uint32_t j) { io2(j); launch_flat<1024>(a2); }});
     vs.push_back({"x   a two-multiply hash instead of the Philox block (NOT the stream: cost probe)", [&](uint32_t j) { io2(j); launch_x<X_CHEAP_RNG>(a2); }});
+    vs.push_back({"x   both fresh records precomputed while the board load is in flight; reset = 4 selects", [&](uint32_t j) { io2(j); launch_x<X_PRE_RESET>(a2); }});
+    vs.push_back({"x   final SCORE (potential computed in-lane) stored as one dword instead of the terminal record", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_SCORE>(a2); }});
     vs.push_back({"x   records with plain (cacheable) loads/stores, outputs nt", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN>(a2); }});
     vs.push_back({"x   records nt, outputs plain", [&](uint32_t j) { io2(j); launch_x<X_OUT_PLAIN>(a2); }});
     vs.push_back({"x   everything plain", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN | X_OUT_PLAIN>(a2); }});
