@@ -25,7 +25,7 @@ struct Variant { std::string name; std::function<void(uint32_t t)> launch; };
 enum { X_ACT_PACKED = 1, X_TERM_PACKED = 2, X_NO_REWARD = 4, X_NO_TERM = 8, X_NO_ACT = 16, X_NO_LASTREC = 32, X_NO_COUNT = 64,
        X_REWARD_U16 = 128, X_COUNT_RMW = 256, X_LASTREC_32 = 512, X_LASTREC_64 = 1024, X_PREFETCH = 2048,
        X_COUNT_SLOAD = 4096, X_LASTREC_DENSE = 8192, X_LASTREC_4B = 16384, X_LASTREC_RING = 32768,
-       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576, X_CHEAP_RNG = 2097152, X_LASTREC_SCORE = 4194304, X_PRE_RESET = 8388608 };
+       X_PREFETCH_BLOCKS = 65536, X_OFF32 = 131072, X_TERM_FIRST = 262144, X_REC_PLAIN = 524288, X_OUT_PLAIN = 1048576, X_CHEAP_RNG = 2097152, X_LASTREC_SCORE = 4194304, X_PRE_RESET = 8388608, X_LASTREC_NT = 16777216, X_LASTREC_SC1 = 33554432 };
 
 template <class T> __device__ __forceinline__ T *off32(T *base, uint32_t i)
 {
@@ -156,7 +156,23 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
     }
     if ((X & X_PREFETCH) && touched == 0x12345677u)
         p.st.ep_counters[0] = touched; // keeps the touch alive
-    if (X & X_LASTREC_SCORE) {
+    if (X & (X_LASTREC_NT | X_LASTREC_SC1)) {
+        const bool fin = o.terminated && valid;
+        const unsigned long long done = __ballot(fin);
+        if (done) {
+            if (fin) {
+                if (X & X_LASTREC_NT)
+                    store_board_nt(p.st.last_record, i, o.terminal);
+                else {
+                    const u32x4 v = {o.terminal.r[0], o.terminal.r[1], o.terminal.r[2], o.terminal.r[3]};
+                    uint4 *dst = p.st.last_record + i;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                }
+            }
+            episodes += (uint32_t)__popcll(done);
+            illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
+        }
+    } else if (X & X_LASTREC_SCORE) {
         // what a 4-byte "final score" bookkeeping would cost: the potential (and so the score) of the finished
         // boards computed in-lane, ONE dword stored per finished board
         const bool fin = o.terminated && valid;
@@ -208,7 +224,7 @@ __global__ void __launch_bounds__(256) kern_x(const g2048::StepArgs p)
             episodes += (uint32_t)__popcll(done);
             illegal_ends += (uint32_t)__popcll(__ballot(fin && !o.legal));
         }
-    } else if (!(X & (X_NO_LASTREC | X_TERM_FIRST | X_LASTREC_SCORE | X_PRE_RESET)))
+    } else if (!(X & (X_NO_LASTREC | X_TERM_FIRST | X_LASTREC_SCORE | X_PRE_RESET | X_LASTREC_NT | X_LASTREC_SC1)))
         record_episode_ends(p, i, o.terminated && valid, !o.legal, o.terminal, episodes, illegal_ends);
     if (!(X & (X_NO_COUNT | X_COUNT_RMW))) {
         if (episodes != 0u && lane == 0u) {
@@ -354,6 +370,8 @@ int main(int argc, char **argv)
     vs.push_back({"f   the same, 1024-lane blocks", [&](uint32_t j) { io2(j); launch_flat<1024>(a2); }});
     vs.push_back({"x   a two-multiply hash instead of the Philox block (NOT the stream: cost probe)", [&](uint32_t j) { io2(j); launch_x<X_CHEAP_RNG>(a2); }});
     vs.push_back({"x   both fresh records precomputed while the board load is in flight; reset = 4 selects", [&](uint32_t j) { io2(j); launch_x<X_PRE_RESET>(a2); }});
+    vs.push_back({"x   terminal record stored nt", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_NT>(a2); }});
+    vs.push_back({"x   terminal record stored sc1 (write-through)", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_SC1>(a2); }});
     vs.push_back({"x   final SCORE (potential computed in-lane) stored as one dword instead of the terminal record", [&](uint32_t j) { io2(j); launch_x<X_LASTREC_SCORE>(a2); }});
     vs.push_back({"x   records with plain (cacheable) loads/stores, outputs nt", [&](uint32_t j) { io2(j); launch_x<X_REC_PLAIN>(a2); }});
     vs.push_back({"x   records nt, outputs plain", [&](uint32_t j) { io2(j); launch_x<X_OUT_PLAIN>(a2); }});
