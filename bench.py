@@ -10,8 +10,15 @@ timed region starts.  Workload = BASELINE configs[2]: B = 2^20 boards per GPU, s
 random policy (actions pre-generated on the device by g2048_fill_random_actions), seed 42.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): rank r owns global boards
-[r*B, (r+1)*B) -- no data-path collective; one RCCL all-gather of the per-board episodic returns at
-the end of the rollout, inside the timed region.  scaling = "weak".
+[r*B, (r+1)*B) -- no data-path collective; one RCCL all-gather of the episodic returns at the end of the
+rollout, inside the timed region and enqueued on the launch stream right behind the K step launches (the
+statistics kernel and the collective start when the last step retires; no host work in between).  The
+all-gather is also the closing barrier of the timed region: no rank's copy completes before every rank has
+contributed, so each rank only synchronises its device afterwards and the elapsed times are MAX-reduced
+over ranks.  `timing` in the JSON splits the region: launch_train_us (K launches, HIP events),
+collective_us (statistics kernel + all-gather, HIP events), host_tail_us (what the wall clock saw on top).
+scaling = "weak".  G2048_BENCH_FORCE_DIST=1 runs exactly this N > 1 code path with a one-rank RCCL process
+group on a one-GPU box (init_process_group("nccl"), the device-tensor all-gather, the NCCL barrier).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- algorithmic bytes (38 B/env-step) / HIP-event time per launch vs the 8 TB/s HBM peak;
@@ -169,22 +176,26 @@ def main():
         sys.exit("bench.py needs a ROCm GPU; the product has no CPU path")
     # G2048_BENCH_BACKEND=gloo + G2048_BENCH_SAME_DEVICE=1: smoke-test the N > 1 code path on a
     # one-GPU box (all ranks share cuda:0, collectives over gloo through host copies).
+    # G2048_BENCH_FORCE_DIST=1: the N > 1 code path (process group, device all-gather, barriers) with ONE rank.
     backend = os.environ.get("G2048_BENCH_BACKEND", "nccl")
+    force_dist = os.environ.get("G2048_BENCH_FORCE_DIST") == "1"
     if os.environ.get("G2048_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_hip()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     from gym2048_amd.batched import Batched2048
     from gym2048_amd.sharding import weak_shard, allgather_returns, allgather_stats, merge_stats
@@ -201,21 +212,24 @@ def main():
     eng.rollout_random(AGE_STEPS)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_gather = backend != "nccl" and dist_on        # gloo smoke test: collectives on host copies
+    stats_buf = torch.empty(168, dtype=torch.uint8, device=dev)          # sizeof(g2048_stats)
+    returns_buf = torch.empty(B, dtype=torch.int32, device=dev) if args.gather == "full" else None
+
     def gather_returns():
         """The path's only exchange, once per rollout: every rank reduces the episodic returns of its shard on
-        the device (one kernel, no host sync) and the per-rank summaries are all-gathered (RCCL over xGMI,
-        latency-bound); --gather full ships every board's last return instead (4 MiB per rank at 2^20)."""
+        the device (one kernel pair, no host sync) and the per-rank summaries are all-gathered (RCCL over xGMI,
+        latency-bound); --gather full ships every board's last return instead (4 MiB per rank at 2^20).
+        Everything is enqueued on the current stream into buffers allocated beforehand."""
         if args.gather == "full":
-            local = eng.last_scores()              # int32[B] returns, from the terminal records (one kernel)
-            if backend != "nccl" and world > 1:    # gloo smoke test: collectives on host copies
-                return allgather_returns(local.cpu(), shard)
-            return allgather_returns(local, shard)
-        local = eng.episode_stats_device()
-        return allgather_stats(local.cpu() if (backend != "nccl" and world > 1) else local)
+            local = eng.last_scores(out=returns_buf)     # int32[B] returns, from the terminal records (one kernel)
+            return allgather_returns(local.cpu() if host_gather else local, shard)
+        local = eng.episode_stats_device(out=stats_buf)
+        return allgather_stats(local.cpu() if host_gather else local)
 
     # ---- device warm-up on a scratch engine (every rank): not steps of the benchmarked engine, whose own
     #      warm-up is exactly the W steps below
@@ -239,10 +253,10 @@ def main():
     actions = eng.random_actions(K, t_first=eng.clock + 1 + W)   # [K][B] u8, resident in HBM
     reward = torch.zeros((K, B), dtype=torch.float32, device=dev)
     terminated = torch.zeros((K, B), dtype=torch.uint8, device=dev)
-    if world > 1:                                        # warm the collective once (communicator setup)
+    if dist_on:                                          # warm the collective once (communicator setup)
         gather_returns()
     plan = eng.prepare_rollout(actions, reward=reward, terminated=terminated)   # argument checks: not timed
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     if W > 0:
         wa = eng.random_actions(W)
         wr = torch.zeros((min(W, 8), B), dtype=torch.float32, device=dev)
@@ -250,22 +264,25 @@ def main():
         for j0 in range(0, W, 8):                        # same kernel, same outputs as the timed steps
             kk = min(8, W - j0)
             eng.rollout(wa[j0:j0 + kk], reward=wr[:kk], terminated=wt[:kk])
-    barrier()
+    barrier()                                            # opening bracket: barrier + synchronize
     ev0.record()                                         # on the (idle) launch stream: start of the launch train
     t0 = time.perf_counter()
     plan.run()                                           # g2048_rollout: EXACTLY K step launches
     ev1.record()
-    # the path's only exchange: once per rollout, N > 1 only (RCCL all-gather of the episodic returns)
-    gathered = gather_returns() if world > 1 else None
-    barrier()
+    # the path's only exchange: once per rollout, N > 1 only.  Enqueued behind the last step launch; at N > 1 it is
+    # also the closing barrier (an all-gather completes on no rank before every rank has contributed)
+    gathered = gather_returns() if dist_on else None
+    ev2.record()
+    torch.cuda.synchronize()                             # closing bracket: [collective +] synchronize
     elapsed = time.perf_counter() - t0
     kernel_region_ms = ev0.elapsed_time(ev1)
+    collective_ms = ev1.elapsed_time(ev2) if dist_on else 0.0
 
-    tmax = torch.tensor([elapsed, kernel_region_ms], dtype=torch.float64,
+    tmax = torch.tensor([elapsed, kernel_region_ms, collective_ms], dtype=torch.float64,
                         device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, kernel_region_ms = float(tmax[0]), float(tmax[1])
+    elapsed, kernel_region_ms, collective_ms = float(tmax[0]), float(tmax[1]), float(tmax[2])
     if gathered is not None:
         assert gathered.numel() == (B * world if args.gather == "full" else 168 * world)
 
@@ -292,7 +309,7 @@ def main():
                            "[K][B] HBM rollout buffers, auto-reset fused",
                    "collective": (f"none per step; one all-gather per rollout of the "
                                   f"{'per-rank episodic-return summaries (168 B each)' if args.gather == 'summary' else 'per-board episodic returns (int32[B] each)'}"
-                                  if world > 1 else "none")},
+                                  if dist_on else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_provenance": traffic_prov,
@@ -301,14 +318,22 @@ def main():
                      "note": (f"the {working_set_mib:.0f} MiB of board records touched per launch sit in the 256 MiB "
                               "Infinity Cache at this batch size, so this is a cache-resident figure; "
                               "extras.streaming_2p24 is the run that streams HBM") if B <= (1 << 22) else None},
+        "timing": {"launch_train_us": kernel_region_ms * 1e3, "collective_us": collective_ms * 1e3,
+                   "host_tail_us": elapsed * 1e6 - (kernel_region_ms + collective_ms) * 1e3,
+                   "note": "max over ranks; wall = launch train (K step launches, HIP events) + collective (statistics "
+                           "kernel + all-gather, HIP events; 0 at N = 1) + host tail (launch-to-start and "
+                           "end-to-host-visible latency of the bracketing synchronize)"},
         "episodes_finished": int(stats["episodes"]), "mean_last_episode_score": stats["mean_last_score"],
     }
+    if force_dist and world == 1:
+        out["config"]["forced_dist"] = f"one-rank {backend} process group: the N > 1 code path on one GPU"
+        out["config"]["collective"] = "one-rank all-gather of the episodic-return summary (forced)" 
     if gathered is not None and args.gather == "summary":
         g = merge_stats(gathered)
         out["global_returns"] = {"episodes": g["episodes"], "mean_last_episode_score": g["mean_last_score"],
                                  "best_last_episode_score": g["last_score_max"]}
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not force_dist:
         extras = {}
         # (a) fused K-step rollout kernel: boards stay in registers; NOT HBM-bound, 38 B model n/a
         eng.rollout_random(8)
@@ -328,27 +353,32 @@ def main():
         except Exception as exc:  # pragma: no cover
             extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
         # (a3) the env-step INCLUDING the observation the reference's step() returns (stack(), game2048_env.py:100):
-        #      step_kernel + onehot_kernel (uint8 [B,16,4,4], +256 B per env-step), best of 3 x 20 steps
+        #      ONE launch per step -- step_kernel<.., HAS_OBS> writes the uint8 [B,16,4,4] one-hot of the record it
+        #      leaves behind (+256 B per env-step, 294 B in all) -- through g2048_rollout over [Ko,B,16,4,4]
+        #      observation buffers (5 GiB at 2^20), best of 3 x Ko launches
         try:
-            obs = torch.zeros((B, 16, 4, 4), dtype=torch.uint8, device=dev)
+            ko = min(K, 20)
+            obs = torch.zeros((ko, B, 16, 4, 4), dtype=torch.uint8, device=dev)
+            oplan = eng.prepare_rollout(actions[:ko], reward=reward[:ko], terminated=terminated[:ko], obs=obs)
+            oplan.run()
             best = None
             for _ in range(3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
-                for j in range(20):
-                    eng.rollout(actions[j:j + 1], reward=reward[j:j + 1], terminated=terminated[j:j + 1])
-                    eng.observe_onehot(out=obs)
+                oplan.run()
                 e1.record()
                 torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / 20
+                us = e0.elapsed_time(e1) * 1e3 / ko
                 best = us if best is None else min(best, us)
-            extras["step_plus_onehot_u8"] = {"us_per_step": best, "steps_per_s": B / (best * 1e-6),
-                                             "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP + 16 + 256,
-                                             "achieved_GBs": (ALGO_BYTES_PER_STEP + 16 + 256) * B / (best * 1e-6) / 1e9}
-            del obs
+            obs_bytes = ALGO_BYTES_PER_STEP + 256
+            extras["step_with_obs_u8"] = {"us_per_step": best, "steps_per_s": B / (best * 1e-6),
+                                          "launches_per_step": 1, "algorithmic_bytes_per_env_step": obs_bytes,
+                                          "achieved_GBs": obs_bytes * B / (best * 1e-6) / 1e9,
+                                          "frac_of_hbm_peak": obs_bytes * B / (best * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            del obs, oplan
         except Exception as exc:  # pragma: no cover
-            extras["step_plus_onehot_u8"] = {"error": str(exc)}
+            extras["step_with_obs_u8"] = {"error": str(exc)}
         # (b) a batch that does not fit L2 + Infinity Cache: 2^24 boards (256 MiB of records).  Every buffer
         #     is written once before timing (first touch), 40 ms of untimed warm-up rollouts, best of 4 timed ones.
         del reward, terminated, actions
@@ -415,7 +445,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

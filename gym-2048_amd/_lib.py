@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class G2048Error(RuntimeError):
@@ -30,6 +30,8 @@ class StepIO(C.Structure):
         ("illegal", C.c_void_p),
         ("highest", C.c_void_p),
         ("terminal_boards", C.c_void_p),
+        ("obs", C.c_void_p),
+        ("obs_dtype", C.c_int32),
     ]
 
 
@@ -94,7 +96,9 @@ SIGNATURES = {
     "g2048_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "g2048_comm_destroy": (C.c_int, [C.c_void_p]),
     "g2048_allgather_returns": (C.c_int, [_E, C.c_void_p, C.c_void_p, _S]),
-    "g2048_allgather_returns_local": (C.c_int, [C.POINTER(_E), C.c_int, C.POINTER(C.c_void_p), C.POINTER(_S)]),
+    "g2048_comm_local_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "g2048_comm_local_destroy": (C.c_int, [C.c_void_p]),
+    "g2048_allgather_returns_local": (C.c_int, [C.c_void_p, C.POINTER(_E), C.POINTER(C.c_void_p), C.POINTER(_S)]),
 }
 COMM_ID_BYTES = 128
 

@@ -180,7 +180,15 @@ class Batched2048:
             x = x.to(self.device)
         return x.contiguous()
 
-    def _io(self, actions, reward, terminated, illegal, highest, terminal_boards):
+    def _check_obs(self, obs, lead=()):
+        """A fused-observation buffer: contiguous ``lead + (n, 16, 4, 4)`` uint8 / float16 / float32 on the engine's device."""
+        if (obs.dtype not in _OBS_DTYPES or tuple(obs.shape) != tuple(lead) + (self.n_envs, 16, 4, 4)
+                or not obs.is_contiguous() or obs.device != self.device):
+            raise ValueError(f"obs must be a contiguous {tuple(lead) + (self.n_envs, 16, 4, 4)} uint8/float16/float32 "
+                             f"tensor on {self.device}")
+        return obs
+
+    def _io(self, actions, reward, terminated, illegal, highest, terminal_boards, obs=None):
         io = StepIO()
         if actions is None:
             io.actions, io.action_dtype = None, _lib.ACT_RANDOM
@@ -191,14 +199,18 @@ class Batched2048:
         for name, t in (("reward", reward), ("terminated", terminated), ("illegal", illegal),
                         ("highest", highest), ("terminal_boards", terminal_boards)):
             setattr(io, name, None if t is None else t.data_ptr())
+        if obs is not None:
+            io.obs, io.obs_dtype = obs.data_ptr(), _OBS_DTYPES[obs.dtype]
         return io
 
-    def step(self, actions=None, auto_reset: bool = True, want_info: bool = True):
+    def step(self, actions=None, auto_reset: bool = True, want_info: bool = True, obs=None):
         """game2048_env.py:76-100 for every board; ``actions=None`` plays the synthetic random policy.
 
         Returns ``(reward, terminated)`` device tensors (views of ``self.reward`` / ``self.terminated``,
         overwritten by the next step).  With ``want_info`` also ``self.illegal``, ``self.highest`` and
-        -- for boards that terminated -- ``self.terminal_boards`` are filled.
+        -- for boards that terminated -- ``self.terminal_boards`` are filled.  ``obs``: a ``[n, 16, 4, 4]``
+        uint8 / float16 / float32 tensor that receives ``stack(board)`` of every board after the step (of the
+        fresh board where an episode ended and ``auto_reset``), written by the SAME launch (:100).
         """
         if actions is not None:
             actions = self._as_device(actions)
@@ -206,21 +218,22 @@ class Batched2048:
                 raise ValueError(f"actions must have shape ({self.n_envs},), got {tuple(actions.shape)}")
         io = self._io(actions, self.reward, self.terminated,
                       self.illegal if want_info else None, self.highest if want_info else None,
-                      self.terminal_boards if want_info else None)
+                      self.terminal_boards if want_info else None, None if obs is None else self._check_obs(obs))
         check(self._lib.g2048_step(self._h, C.byref(io), int(auto_reset), self._stream()))
         self._fresh = False
         return self.reward, self.terminated
 
     def rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None, auto_reset: bool = True,
-                fused: bool = False, terminal_boards=None):
+                fused: bool = False, terminal_boards=None, obs=None):
         """``k`` steps without returning to Python: ``actions`` is ``[k, n]`` (or ``k`` as an int for
         the synthetic random policy); optional outputs are ``[k, n]`` rollout buffers (``terminal_boards``:
-        ``[k, n, 16]``, rows written only where an episode ended; not with ``fused``).  ``fused=True`` runs
-        them as ONE launch with the boards in registers (same outputs, ``g2048_rollout_fused``)."""
-        self.prepare_rollout(actions, reward, terminated, illegal, highest, auto_reset, fused, terminal_boards).run()
+        ``[k, n, 16]``, rows written only where an episode ended; ``obs``: ``[k, n, 16, 4, 4]``, the one-hot
+        observation after every step, written by the step launches themselves; neither with ``fused``).
+        ``fused=True`` runs them as ONE launch with the boards in registers (same outputs, ``g2048_rollout_fused``)."""
+        self.prepare_rollout(actions, reward, terminated, illegal, highest, auto_reset, fused, terminal_boards, obs).run()
 
     def prepare_rollout(self, actions, reward=None, terminated=None, illegal=None, highest=None,
-                        auto_reset: bool = True, fused: bool = False, terminal_boards=None):
+                        auto_reset: bool = True, fused: bool = False, terminal_boards=None, obs=None):
         """Validate the buffers of a rollout and build its launch descriptor once; ``.run()`` then is a
         single call into ``g2048_rollout`` (the argument checks stay out of a latency-critical loop)."""
         if isinstance(actions, int):
@@ -242,9 +255,11 @@ class Batched2048:
                                             or terminal_boards.dtype != torch.uint8
                                             or not terminal_boards.is_contiguous() or terminal_boards.device != self.device):
             raise ValueError("terminal_boards must be a contiguous uint8 [k, n_envs, 16] tensor on the engine's device")
-        io = self._io(act, reward, terminated, illegal, highest, terminal_boards)
+        if obs is not None:
+            self._check_obs(obs, (k,))
+        io = self._io(act, reward, terminated, illegal, highest, terminal_boards, obs)
         fn = self._lib.g2048_rollout_fused if fused else self._lib.g2048_rollout
-        return _RolloutPlan(self, fn, k, io, int(auto_reset), (act, reward, terminated, illegal, highest, terminal_boards))
+        return _RolloutPlan(self, fn, k, io, int(auto_reset), (act, reward, terminated, illegal, highest, terminal_boards, obs))
 
     def rollout_random(self, k_steps: int):
         """ONE fused launch: ``k_steps`` of the synthetic random policy, boards kept in registers."""
@@ -318,8 +333,9 @@ class Batched2048:
         """``stack()`` (game2048_env.py:17-32) for the batch: ``[n, 16, 4, 4]`` of ``dtype``."""
         if out is None:
             out = torch.empty((self.n_envs, 16, 4, 4), dtype=dtype, device=self.device)
-        if out.dtype not in _OBS_DTYPES or tuple(out.shape) != (self.n_envs, 16, 4, 4) or not out.is_contiguous():
-            raise ValueError("one-hot output must be a contiguous [n,16,4,4] uint8/float16/float32 tensor")
+        if (out.dtype not in _OBS_DTYPES or tuple(out.shape) != (self.n_envs, 16, 4, 4) or not out.is_contiguous()
+                or out.device != self.device):
+            raise ValueError(f"one-hot output must be a contiguous [n,16,4,4] uint8/float16/float32 tensor on {self.device}")
         check(self._lib.g2048_onehot(self._h, out.data_ptr(), _OBS_DTYPES[out.dtype], self._stream()))
         return out
 

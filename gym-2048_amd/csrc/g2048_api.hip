@@ -52,6 +52,8 @@ struct g2048_engine {
     g2048::StatsOut *stats_dev = nullptr;
     unsigned long long *stats_partials = nullptr; // stage-1 output of the statistics reduction
     void *scratch = nullptr; // staging for host-side get/set of boards and scores (16 B per board), lazily
+    int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
+                                // in flight on one stream must not be clobbered by a get_* call on another
 };
 
 namespace {
@@ -77,6 +79,8 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
         a.illegal = io->illegal;
         a.highest = io->highest;
         a.terminal_boards = reinterpret_cast<uint4 *>(io->terminal_boards);
+        a.obs = io->obs;
+        a.obs_dtype = static_cast<uint32_t>(io->obs_dtype);
     }
     a.n = static_cast<uint32_t>(e->n);
     a.board_offset = static_cast<uint32_t>(e->board_offset);
@@ -89,6 +93,8 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
     a.auto_reset = auto_reset ? 1u : 0u;
     return a;
 }
+
+size_t obs_board_bytes(int dtype) { return static_cast<size_t>(256) << (dtype < 0 ? 0 : dtype); } // 16 channels x 16 cells
 
 size_t action_size(int dtype)
 {
@@ -113,6 +119,12 @@ int check_io(const g2048_step_io *io)
         (reinterpret_cast<uintptr_t>(io->reward) & 3u) || (reinterpret_cast<uintptr_t>(io->terminal_boards) & 15u))
         return fail(G2048_ERR_INVALID, "misaligned buffer: actions need their element size, reward 4 bytes, "
                                        "terminal_boards 16 bytes");
+    if (io->obs) {
+        if (io->obs_dtype < G2048_OBS_U8 || io->obs_dtype > G2048_OBS_F32)
+            return fail(G2048_ERR_INVALID, "unknown obs_dtype %d", io->obs_dtype);
+        if (reinterpret_cast<uintptr_t>(io->obs) & 15u)
+            return fail(G2048_ERR_INVALID, "misaligned buffer: obs needs 16 bytes");
+    }
     return G2048_OK;
 }
 
@@ -122,7 +134,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 8; }
+int g2048_abi_version(void) { return 9; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -196,6 +208,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipFree(e->st.rng);
         if (e->scratch)
             (void)hipFree(e->scratch);
+        if (e->returns)
+            (void)hipFree(e->returns);
         if (e->stats_partials)
             (void)hipFree(e->stats_partials);
         err = hipFree(e->slab);
@@ -308,6 +322,7 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         if (s.illegal) s.illegal = io->illegal + off;
         if (s.highest) s.highest = io->highest + off;
         if (s.terminal_boards) s.terminal_boards = io->terminal_boards + off * 16;
+        if (s.obs) s.obs = static_cast<char *>(io->obs) + off * obs_board_bytes(io->obs_dtype);
         e->t += 1;
         e->fresh = 0;
         const g2048::StepArgs a = make_args(e, &s, auto_reset);
@@ -326,8 +341,8 @@ int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *
         return fail(G2048_ERR_INVALID, "engine is NULL");
     if (int rc = check_io(io))
         return rc;
-    if (io->terminal_boards)
-        return fail(G2048_ERR_INVALID, "g2048_rollout_fused does not write terminal_boards");
+    if (io->terminal_boards || io->obs)
+        return fail(G2048_ERR_INVALID, "g2048_rollout_fused writes neither terminal_boards nor obs");
     if (e->st.rng)
         return fail(G2048_ERR_INVALID, "g2048_rollout_fused draws from the spawn stream; not available in numpy-RNG mode");
     if (k_steps == 0)
@@ -475,6 +490,33 @@ static int ensure_scratch(g2048_engine *e)
         return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) for the host staging buffer failed: %s", (size_t)(e->n * 16),
                     hipGetErrorString(err));
     }
+    return G2048_OK;
+}
+
+static int ensure_returns(g2048_engine *e)
+{
+    if (e->returns)
+        return G2048_OK;
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&e->returns), e->n * 4);
+    if (err != hipSuccess) {
+        e->returns = nullptr;
+        return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) for the all-gather send buffer failed: %s", (size_t)(e->n * 4),
+                    hipGetErrorString(err));
+    }
+    return G2048_OK;
+}
+
+// The device a pointer lives on (engine-less entry points launch there, whatever the caller's current device is).
+static int set_device_of(const void *p)
+{
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(G2048_ERR_INVALID, "buffer %p is not device memory of this process", p);
+    }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+        return fail(G2048_ERR_INVALID, "buffer %p is not device memory", p);
+    G2048_HIP(hipSetDevice(attr.device));
     return G2048_OK;
 }
 
@@ -685,6 +727,10 @@ int g2048_augment(const uint8_t *boards, const uint8_t *next_boards, const uint8
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (n > 0x1fffffffull)
         return fail(G2048_ERR_INVALID, "n too large");
+    if (n == 0)
+        return G2048_OK;
+    if (int rc = set_device_of(boards))
+        return rc;
     G2048_HIP(g2048::launch_augment(reinterpret_cast<const uint4 *>(boards), reinterpret_cast<const uint4 *>(next_boards),
                                     actions, static_cast<uint32_t>(n), reinterpret_cast<uint4 *>(boards_out),
                                     reinterpret_cast<uint4 *>(next_out), actions_out, static_cast<hipStream_t>(stream)));
@@ -752,6 +798,10 @@ int g2048_canonicalize(uint8_t *boards, uint8_t *next_boards, uint8_t *actions, 
         return fail(G2048_ERR_INVALID, "n too large");
     if ((reinterpret_cast<uintptr_t>(boards) | reinterpret_cast<uintptr_t>(next_boards)) & 15u)
         return fail(G2048_ERR_INVALID, "board buffers must be 16-byte aligned");
+    if (n == 0)
+        return G2048_OK;
+    if (int rc = set_device_of(boards))
+        return rc;
     G2048_HIP(g2048::launch_canonicalize(reinterpret_cast<uint4 *>(boards), reinterpret_cast<uint4 *>(next_boards), actions,
                                          static_cast<uint32_t>(n), symmetry_out, static_cast<hipStream_t>(stream)));
     return G2048_OK;
@@ -827,6 +877,12 @@ struct g2048_comm {
     int world = 0, rank = 0, device = 0;
 };
 
+struct g2048_comm_local {
+    int n = 0;
+    int devices[G2048_COMM_LOCAL_MAX] = {};
+    ncclComm_t comms[G2048_COMM_LOCAL_MAX] = {};
+};
+
 extern "C" {
 
 int g2048_comm_unique_id(uint8_t id[G2048_COMM_ID_BYTES])
@@ -889,65 +945,99 @@ int g2048_allgather_returns(const g2048_engine *ce, g2048_comm *c, int32_t *out,
     if (c->device != e->device)
         return fail(G2048_ERR_INVALID, "communicator is on device %d, engine on device %d", c->device, e->device);
     G2048_HIP(hipSetDevice(e->device));
-    if (int rc = ensure_scratch(e))
+    if (int rc = ensure_returns(e))
         return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // the returns are the scores of last_record: materialise int32[n] in the staging buffer, then ONE
+    // the returns are the scores of last_record: materialise int32[n] in the engine's send buffer, then ONE
     // all-gather (equal shards: rank r's n returns land at out[r * n]), all on the caller's stream
-    int32_t *send = static_cast<int32_t *>(e->scratch);
+    int32_t *send = e->returns;
     G2048_HIP(g2048::launch_export_last_scores(e->st, static_cast<uint32_t>(e->n), send, s));
     G2048_NCCL(g_rccl.AllGather(send, out, e->n, ncclInt32, c->comm, s));
     return G2048_OK;
 }
 
-int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, int32_t *const *outs, void *const *streams)
+int g2048_comm_local_create(const int *devices, int n_devices, g2048_comm_local **out)
 {
-    if (!engines || !outs || n_engines < 1)
-        return fail(G2048_ERR_INVALID, "bad argument");
-    if (n_engines > 64)
-        return fail(G2048_ERR_INVALID, "at most 64 engines");
+    if (!devices || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > G2048_COMM_LOCAL_MAX)
+        return fail(G2048_ERR_INVALID, "n_devices %d out of range 1..%d", n_devices, G2048_COMM_LOCAL_MAX);
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = a + 1; b < n_devices; ++b)
+            if (devices[a] == devices[b])
+                return fail(G2048_ERR_INVALID, "device %d listed twice: one communicator per device", devices[a]);
+    if (int rc = load_rccl())
+        return rc;
+    g2048_comm_local *c = new (std::nothrow) g2048_comm_local;
+    if (!c)
+        return fail(G2048_ERR_NOMEM, "out of host memory");
+    c->n = n_devices;
+    for (int r = 0; r < n_devices; ++r)
+        c->devices[r] = devices[r];
+    const ncclResult_t res = g_rccl.CommInitAll(c->comms, n_devices, c->devices); // the expensive part: done ONCE
+    if (res != ncclSuccess) {
+        delete c;
+        return fail(G2048_ERR_HIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(res));
+    }
+    *out = c;
+    return G2048_OK;
+}
+
+int g2048_comm_local_destroy(g2048_comm_local *c)
+{
+    if (!c)
+        return G2048_OK;
+    ncclResult_t first = ncclSuccess;
+    for (int r = 0; r < c->n; ++r) {
+        const ncclResult_t res = c->comms[r] ? g_rccl.CommDestroy(c->comms[r]) : ncclSuccess;
+        if (res != ncclSuccess && first == ncclSuccess)
+            first = res;
+    }
+    delete c;
+    if (first != ncclSuccess)
+        return fail(G2048_ERR_HIP, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(first));
+    return G2048_OK;
+}
+
+int g2048_allgather_returns_local(g2048_comm_local *c, g2048_engine *const *engines, int32_t *const *outs,
+                                  void *const *streams)
+{
+    if (!c || !engines || !outs)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    const int n_engines = c->n;
     for (int r = 0; r < n_engines; ++r) {
         if (!engines[r] || !outs[r])
             return fail(G2048_ERR_INVALID, "engine or output %d is NULL", r);
+        if (engines[r]->device != c->devices[r])
+            return fail(G2048_ERR_INVALID, "engine %d is on device %d, the communicator's slot %d on device %d", r,
+                        engines[r]->device, r, c->devices[r]);
         if (engines[r]->n != engines[0]->n)
             return fail(G2048_ERR_INVALID, "engines must hold equal shards (engine %d has %llu boards, engine 0 %llu)", r,
                         (unsigned long long)engines[r]->n, (unsigned long long)engines[0]->n);
     }
-    if (int rc = load_rccl())
-        return rc;
-    int devs[64];
-    ncclComm_t comms[64];
     for (int r = 0; r < n_engines; ++r) {
-        devs[r] = engines[r]->device;
-        G2048_HIP(hipSetDevice(devs[r]));
-        if (int rc = ensure_scratch(engines[r]))
+        G2048_HIP(hipSetDevice(c->devices[r]));
+        if (int rc = ensure_returns(engines[r]))
             return rc;
-        G2048_HIP(g2048::launch_export_last_scores(engines[r]->st, static_cast<uint32_t>(engines[r]->n),
-                                                   static_cast<int32_t *>(engines[r]->scratch),
+        G2048_HIP(g2048::launch_export_last_scores(engines[r]->st, static_cast<uint32_t>(engines[r]->n), engines[r]->returns,
                                                    static_cast<hipStream_t>(streams ? streams[r] : nullptr)));
     }
-    G2048_NCCL(g_rccl.CommInitAll(comms, n_engines, devs)); // single process, one communicator per device
-    int rc = G2048_OK;
     ncclResult_t res = g_rccl.GroupStart();
     for (int r = 0; r < n_engines && res == ncclSuccess; ++r) {
-        if (hipSetDevice(devs[r]) != hipSuccess) {
+        if (hipSetDevice(c->devices[r]) != hipSuccess) {
             res = ncclUnhandledCudaError;
             break;
         }
-        res = g_rccl.AllGather(engines[r]->scratch, outs[r], engines[r]->n, ncclInt32, comms[r],
+        res = g_rccl.AllGather(engines[r]->returns, outs[r], engines[r]->n, ncclInt32, c->comms[r],
                                static_cast<hipStream_t>(streams ? streams[r] : nullptr));
     }
     const ncclResult_t end = g_rccl.GroupEnd();
     if (res == ncclSuccess)
         res = end;
-    for (int r = 0; r < n_engines; ++r) {
-        if (hipSetDevice(devs[r]) == hipSuccess)
-            (void)hipStreamSynchronize(static_cast<hipStream_t>(streams ? streams[r] : nullptr));
-        (void)g_rccl.CommDestroy(comms[r]);
-    }
     if (res != ncclSuccess)
-        rc = fail(G2048_ERR_HIP, "RCCL all-gather failed: %s", g_rccl.GetErrorString(res));
-    return rc;
+        return fail(G2048_ERR_HIP, "RCCL all-gather failed: %s", g_rccl.GetErrorString(res));
+    return G2048_OK; // enqueued: outs[r] is complete when streams[r] reaches this point
 }
 
 } // extern "C"

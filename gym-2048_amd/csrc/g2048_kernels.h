@@ -39,6 +39,8 @@ struct StepArgs {
     uint8_t *illegal;
     uint8_t *highest;
     uint4 *terminal_boards;
+    void *obs;          // [n][16][4][4] one-hot observation of the board AFTER the step (and its auto-reset), or NULL
+    uint32_t obs_dtype; // G2048_OBS_*
     uint32_t n;
     uint32_t board_offset;
     uint32_t seed_lo, seed_hi;

@@ -40,6 +40,13 @@ __device__ __forceinline__ void store_board_nt(uint4 *boards, uint32_t i, const 
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(boards) + i);
 }
 
+// one 16-byte piece of an observation: written once and read by somebody else's kernel, so a streaming (nt) store
+__device__ __forceinline__ void store_chunk_nt(uint4 *out, uint64_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const u32x4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out) + g);
+}
+
 __device__ __forceinline__ Board load_board(const uint4 *boards, uint32_t i)
 {
     const uint4 v = boards[i];
@@ -173,6 +180,73 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
     *reinterpret_cast<ulonglong2 *>(c.slot) = v;
 }
 
+// ------------------------------------------------------------ observation fused into the step
+// stack() (game2048_env.py:17-32) of the record a step leaves behind -- what Game2048Env.step returns first
+// (game2048_env.py:100) -- written by the step kernel itself: no second launch and no re-read of the records.
+//
+// The 64 boards of a wavefront are consecutive, so their observations are ONE contiguous piece of the output
+// (16 / 32 / 64 KiB for u8 / f16 / f32).  The wave parks its 64 records in LDS (1 KiB) and writes that piece
+// with fully coalesced 16-byte streaming stores: in store s, lane l writes chunk s * 64 + l.  Per dtype a chunk is
+//   u8 : one channel (16 cells) of one board      -> needs the whole record     (ds_read_b128, 4 boards per store)
+//   f16: half a channel (8 cells)                 -> two words of the record    (ds_read_b64,  2 boards per store)
+//   f32: one row of one channel (4 cells)         -> one word of the record     (ds_read_b32,  1 board per store)
+// Byte compare of four cells at once: t = cells ^ splat(channel) has every byte < 0x40, so 0x80808080 - t has
+// bit 7 set exactly in the bytes where t == 0 and no borrow crosses a byte.
+__device__ __forceinline__ uint32_t eq_flags(uint32_t cells, uint32_t splat) { return (kHigh1 - (cells ^ splat)) & kHigh1; }
+__device__ __forceinline__ uint32_t eq_ones(uint32_t cells, uint32_t splat) { return ((kHigh1 - (cells ^ splat)) >> 7) & 0x01010101u; }
+
+template <bool FULL>
+__device__ __forceinline__ void emit_onehot(uint4 *wave_recs, const Board &rec, void *obs, uint32_t obs_dtype,
+                                            uint32_t wave_first, uint32_t n)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    wave_recs[lane] = make_uint4(rec.r[0], rec.r[1], rec.r[2] & kCellBits, rec.r[3] & kCellBits);
+    // same-wave LDS accesses execute in program order; the fences keep the compiler from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // boards of this wave that exist (ragged last block only)
+    const uint32_t n_here = FULL ? 64u : (wave_first < n ? (n - wave_first < 64u ? n - wave_first : 64u) : 0u);
+    if (obs_dtype == 0u) {
+        uint4 *out = static_cast<uint4 *>(obs) + static_cast<uint64_t>(wave_first) * 16u;
+        const uint32_t splat = (lane & 15u) * 0x01010101u;
+#pragma unroll
+        for (uint32_t s = 0; s < 16u; ++s) {
+            const uint32_t b = s * 4u + (lane >> 4);
+            const uint4 v = wave_recs[b];
+            if (FULL || b < n_here)
+                store_chunk_nt(out, s * 64u + lane, eq_ones(v.x, splat), eq_ones(v.y, splat), eq_ones(v.z, splat),
+                               eq_ones(v.w, splat));
+        }
+    } else if (obs_dtype == 1u) {
+        uint4 *out = static_cast<uint4 *>(obs) + static_cast<uint64_t>(wave_first) * 32u;
+        const uint32_t splat = ((lane >> 1) & 15u) * 0x01010101u;
+        const uint2 *halves = reinterpret_cast<const uint2 *>(wave_recs) + (lane & 1u); // rows 0,1 or rows 2,3
+#pragma unroll
+        for (uint32_t s = 0; s < 32u; ++s) {
+            const uint32_t b = s * 2u + (lane >> 5);
+            const uint2 v = halves[b * 2u];
+            // 0x3c in the bytes that match (fp16 1.0 = 0x3c00), then each byte becomes the high byte of a half
+            const uint32_t f0 = eq_flags(v.x, splat), f1 = eq_flags(v.y, splat);
+            const uint32_t g0 = (f0 - (f0 >> 7)) & 0x3c3c3c3cu, g1 = (f1 - (f1 >> 7)) & 0x3c3c3c3cu;
+            if (FULL || b < n_here)
+                store_chunk_nt(out, s * 64u + lane, g2048_perm(g0, g0, 0x010c000cu), g2048_perm(g0, g0, 0x030c020cu),
+                               g2048_perm(g1, g1, 0x010c000cu), g2048_perm(g1, g1, 0x030c020cu));
+        }
+    } else {
+        uint4 *out = static_cast<uint4 *>(obs) + static_cast<uint64_t>(wave_first) * 64u;
+        const uint32_t splat = (lane >> 2) * 0x01010101u;
+        const uint32_t *rows = reinterpret_cast<const uint32_t *>(wave_recs) + (lane & 3u);
+#pragma unroll 16
+        for (uint32_t s = 0; s < 64u; ++s) {
+            const uint32_t f = eq_flags(rows[s * 4u], splat);             // 0x80 in the matching bytes
+            const uint32_t g = (f - (f >> 7)) & 0x3f3f3f3fu;              // 0x3f there: fp32 1.0 = 0x3f800000
+            if (FULL || s < n_here)
+                store_chunk_nt(out, s * 64u + lane, g2048_perm(g, f, 0x04000c0cu), g2048_perm(g, f, 0x05010c0cu),
+                               g2048_perm(g, f, 0x06020c0cu), g2048_perm(g, f, 0x07030c0cu));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
@@ -196,16 +270,22 @@ struct StepTail {
     float illegal_reward;
     uint32_t max_exp;
     uint32_t auto_reset;
+    void *obs;          // HAS_OBS kernels only
+    uint32_t obs_dtype;
 };
 
 // STD: the standard configuration -- reward and terminated present, no illegal / highest / terminal_boards, no
 // max_tile -- so none of the "is this wanted" branches exists (a taken scalar branch costs a wavefront ~20 cycles).
-template <int ACT, bool FULL, bool STD>
+// HAS_OBS: the step also returns its observation (game2048_env.py:100 `return stack(self.Matrix), ...`): the
+// one-hot of the record it leaves behind is written by emit_onehot (+256 / 512 / 1 024 B per board; the dtype is a
+// wave-uniform switch, one taken branch against hundreds of store-bound instructions).
+template <int ACT, bool FULL, bool STD, bool HAS_OBS>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
             uint32_t seed_hi, uint32_t t_lo, uint32_t t_hi, uint32_t n, float *reward, const StepTail tail)
 {
     __shared__ WaveTables s_tables[kBlock / 64];
+    __shared__ uint4 s_recs[HAS_OBS ? kBlock : 1];
     StepArgs p{};
     p.st.boards = boards;
     p.st.last_record = tail.last_record;
@@ -261,6 +341,8 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
             __builtin_nontemporal_store(static_cast<uint8_t>(top), p.highest + i);
     }
     flush_episode_counts(counters, episodes, illegal_ends);
+    if constexpr (HAS_OBS)
+        emit_onehot<FULL>(s_recs + (threadIdx.x & ~63u), rec, tail.obs, tail.obs_dtype, i_raw & ~63u, n);
 }
 
 // ------------------------------------------------------------------------- fused rollout
@@ -293,6 +375,34 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
 // The same k steps g2048_rollout performs with k launches, in ONE launch: the record stays in
 // registers, each step reads action[j][i] and writes reward[j][i] / terminated[j][i] (stride = elements
 // between consecutive steps).  Bit-identical outputs; 6 B of traffic per env-step instead of 38.
+//
+// The only memory latency on a step's critical path is its action byte, and the only thing a step must not wait
+// for is the write acknowledgement of the previous steps' stores.  So the action loads run kPrefetch steps ahead
+// of the arithmetic, as a software pipeline in registers: the step loop is unrolled 2 * kPrefetch times over TWO
+// register sets -- steps of the first half consume set A and refill set B, the second half consumes B and refills
+// A -- so every in-flight action has a fixed register whose old value is dead when the new load is issued (rotating
+// registers with moves, or reloading the slot that is being consumed, makes the compiler wait for everything at the
+// loop latch).  Step j then waits with s_waitcnt vmcnt(n > 0) for a load issued kPrefetch steps -- thousands of
+// cycles -- earlier, and the younger loads and stores stay in flight.  The I/O pointers are __restrict__, which
+// lets the compiler issue a step's load ahead of the previous steps' stores.
+constexpr uint32_t kPrefetch = 4;
+
+// the in-flight actions keep their memory type (a conversion next to the load would be a use of its result: the
+// wait would land there instead of kPrefetch steps later)
+template <int ACT> struct RawAction { typedef uint32_t type; };
+template <> struct RawAction<1> { typedef uint8_t type; };
+template <> struct RawAction<2> { typedef int32_t type; };
+template <> struct RawAction<3> { typedef long long type; };
+
+template <int ACT>
+__device__ __forceinline__ typename RawAction<ACT>::type load_action_at(const void *__restrict__ actions, size_t idx)
+{
+    if constexpr (ACT == 0)
+        return 0u;
+    else
+        return __builtin_nontemporal_load(static_cast<const typename RawAction<ACT>::type *>(actions) + idx);
+}
+
 template <int ACT>
 __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p, uint64_t stride)
 {
@@ -300,39 +410,73 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
     const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
+    const void *__restrict__ actions = p.actions;
+    float *__restrict__ reward = p.reward;
+    uint8_t *__restrict__ terminated = p.terminated;
+    uint8_t *__restrict__ illegal = p.illegal;
+    uint8_t *__restrict__ highest_out = p.highest;
+    const uint32_t k = p.k_steps;
+    // the first kPrefetch actions (register set A) are requested before anything else
+    typename RawAction<ACT>::type ahead[kPrefetch];
+#pragma unroll
+    for (uint32_t q = 0; q < kPrefetch; ++q) {
+        ahead[q] = load_action_at<ACT>(actions, static_cast<size_t>(q < k ? q : k - 1u) * stride + i);
+        asm volatile("" ::: "memory"); // issue order = consumption order (the scheduler reverses them otherwise, and
+                                       // the loop's first wait would then have to cover all of them)
+    }
     Board rec = load_board_nt(p.st.boards, i);
     const LdsTables tb = stage_tables(s_tables, load_tables_piece());
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
     uint32_t episodes = 0, illegal_ends = 0;
-    for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
+    // step j with its action; t advances with it
+    auto one_step = [&](uint32_t j, uint32_t action_in) {
         const size_t o_idx = static_cast<size_t>(j) * stride + i;
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
                                       p.seed_lo, p.seed_hi);
-        uint32_t action;
-        if constexpr (ACT == 0)
-            action = w.w[3] >> 30;
-        else if constexpr (ACT == 1)
-            action = __builtin_nontemporal_load(static_cast<const uint8_t *>(p.actions) + o_idx) & 3u;
-        else if constexpr (ACT == 2)
-            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(p.actions) + o_idx)) & 3u;
-        else
-            action = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(p.actions) + o_idx)) & 3u;
+        ++t;
+        const uint32_t action = ACT == 0 ? w.w[3] >> 30 : action_in & 3u;
         const StepOut o = play_record(rec, action, w, p.max_exp, tb);
         record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
         if (valid) {
-            if (p.reward)
-                __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + o_idx);
-            if (p.terminated)
-                __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + o_idx);
-            if (p.illegal)
-                __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + o_idx);
-            if (p.highest)
-                __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(rec))), p.highest + o_idx);
+            if (reward)
+                __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, reward + o_idx);
+            if (terminated)
+                __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), terminated + o_idx);
+            if (illegal)
+                __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), illegal + o_idx);
+            if (highest_out)
+                __builtin_nontemporal_store(static_cast<uint8_t>(highest(record_cells(rec))), highest_out + o_idx);
         }
         if (o.terminated && p.auto_reset != 0)
             reset_record(rec, o, w, tb);
+    };
+    // past the end the last step's action is fetched again and never used (an unconditional load: a conditional one
+    // would be waited for where the branches join)
+    auto fetch = [&](uint32_t j) { return load_action_at<ACT>(actions, static_cast<size_t>(j < k ? j : k - 1u) * stride + i); };
+    typename RawAction<ACT>::type set_b[kPrefetch];
+    uint32_t j0 = 0;
+    for (; j0 + 2u * kPrefetch <= k; j0 += 2u * kPrefetch) { // whole double groups
+#pragma unroll
+        for (uint32_t q = 0; q < kPrefetch; ++q) {
+            if constexpr (ACT != 0)
+                set_b[q] = fetch(j0 + q + kPrefetch);
+            one_step(j0 + q, static_cast<uint32_t>(ahead[q]));
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kPrefetch; ++q) {
+            if constexpr (ACT != 0)
+                ahead[q] = fetch(j0 + q + 2u * kPrefetch);
+            one_step(j0 + kPrefetch + q, static_cast<uint32_t>(set_b[q]));
+        }
     }
+    // the last k % (2 * kPrefetch) steps: the first kPrefetch of them have their actions in flight already
+#pragma unroll
+    for (uint32_t q = 0; q < kPrefetch; ++q)
+        if (j0 + q < k)
+            one_step(j0 + q, static_cast<uint32_t>(ahead[q]));
+    for (uint32_t j = j0 + kPrefetch; j < k; ++j)
+        one_step(j, static_cast<uint32_t>(fetch(j)));
     if (valid)
         store_board_nt(p.st.boards, i, rec);
     flush_episode_counts(counters, episodes, illegal_ends);
@@ -653,13 +797,6 @@ __global__ void __launch_bounds__(kBlock) fill_actions_kernel(uint8_t *out, uint
 //   u8 : chunk = one channel (16 cells)            16 chunks / board
 //   f16: chunk = half a channel (8 cells)          32 chunks / board
 //   f32: chunk = one row of one channel (4 cells)  64 chunks / board
-// the observation is written once and read by somebody else's kernel: streaming (nt) stores
-__device__ __forceinline__ void store_chunk_nt(uint4 *out, uint64_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    const u32x4 v = {a, b, c, d};
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out) + g);
-}
-
 template <int OBS>
 __global__ void __launch_bounds__(kBlock) onehot_kernel(const uint4 *__restrict__ boards, uint64_t chunks,
                                                         uint4 *__restrict__ out)
@@ -945,15 +1082,20 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     const dim3 g = grid_for(a.n), b(kBlock);
     const bool full = a.n % kBlock == 0;
     const StepTail tail{a.terminated, a.st.last_record, a.illegal, a.highest, a.terminal_boards, a.illegal_reward, a.max_exp,
-                        a.auto_reset};
+                        a.auto_reset, a.obs, a.obs_dtype};
+#define G2048_STEP_LAUNCH(ACT, FULL, STD, OBS)                                                                          \
+    hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,         \
+                       a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail)
 #define G2048_STEP(ACT, FULL)                                                                                           \
     do {                                                                                                                \
-        if (standard)                                                                                                   \
-            hipLaunchKernelGGL((step_kernel<ACT, FULL, true>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,      \
-                               a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail);                \
+        if (standard && a.obs)                                                                                          \
+            G2048_STEP_LAUNCH(ACT, FULL, true, true);                                                                   \
+        else if (standard)                                                                                              \
+            G2048_STEP_LAUNCH(ACT, FULL, true, false);                                                                  \
+        else if (a.obs)                                                                                                 \
+            G2048_STEP_LAUNCH(ACT, FULL, false, true);                                                                  \
         else                                                                                                            \
-            hipLaunchKernelGGL((step_kernel<ACT, FULL, false>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,     \
-                               a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail);                \
+            G2048_STEP_LAUNCH(ACT, FULL, false, false);                                                                 \
     } while (0)
     const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0;
     switch (action_dtype * 2 + (full ? 1 : 0)) {
@@ -966,6 +1108,7 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     case 6: G2048_STEP(3, false); break;
     case 7: G2048_STEP(3, true); break;
 #undef G2048_STEP
+#undef G2048_STEP_LAUNCH
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1044,6 +1187,8 @@ hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s)
         const uint32_t n_waves = (a.n + 63u) / 64u;
         hipLaunchKernelGGL(reset_list_numpy_kernel, dim3((n_waves + kListGroup - 1u) / kListGroup), dim3(64), 0, s, a, n_waves);
     }
+    if (a.obs) // the observation of this mode comes from the stand-alone kernel: the resets above run after the step kernel
+        return launch_onehot(a.st.boards, a.n, a.obs, static_cast<int>(a.obs_dtype), s);
     return hipGetLastError();
 }
 

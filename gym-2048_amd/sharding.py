@@ -48,8 +48,8 @@ def allgather_returns(local_returns: torch.Tensor, shard: Shard) -> torch.Tensor
     Equal shards use one ``all_gather_into_tensor`` (one RCCL all-gather over xGMI); ragged shards
     pad to the largest shard first.
     """
-    if shard.world_size == 1 or not dist.is_initialized():
-        return local_returns.clone()
+    if not dist.is_initialized():               # no process group: nothing to exchange
+        return local_returns.clone()            # (a ONE-rank group still runs the collective: bench.py's forced-dist mode)
     base, extra = divmod(shard.n_global, shard.world_size)
     n_max = base + (1 if extra else 0)
     send = local_returns
@@ -69,7 +69,7 @@ def allgather_stats(local_stats: torch.Tensor) -> torch.Tensor:
     """All-gather the per-rank episodic-return SUMMARY (``Batched2048.episode_stats_device()``: the C struct
     g2048_stats as ``uint8 [168]``) -> ``uint8 [world, 168]`` on every rank.  A few hundred bytes per rank:
     one latency-bound RCCL all-gather per rollout (SURVEY 8e's first option)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local_stats.reshape(1, -1).clone()
     flat = local_stats.contiguous().reshape(-1)
     out = torch.empty(dist.get_world_size() * flat.numel(), dtype=flat.dtype, device=flat.device)

@@ -26,7 +26,14 @@
  *    exactly 16 bytes per board -- there is no separate score array.  g2048_get/set_boards and
  *    g2048_get/set_scores convert to and from plain arrays; g2048_records_ptr exposes the records
  *    (cells = byte & 0x1f).  Scores are exact in 0 .. 2^24 - 1.
- *  - An engine is not thread-safe; use one engine per device per process.
+ *  - An engine is not thread-safe; use one engine per device per process.  All calls on one engine must also be
+ *    STREAM-ORDERED: issue them on one stream, or order the streams with events.  The episode counters are
+ *    updated without atomics (one wavefront per counter pair per launch), the statistics reduction has one
+ *    scratch area per engine, and the get / set calls with host buffers share one staging buffer -- two calls in flight
+ *    on different streams can corrupt each other's results.  (The all-gather has its own send buffer.)
+ *  - Value ranges: cell exponents 0..30 (set_boards takes them mod 32; a merge of two 2^31 tiles would overflow the
+ *    5-bit field into the deficit bits -- unreachable in play, where the largest tile is 2^17); scores
+ *    0 .. 2^24 - 1 (host buffers are range-checked, device buffers are reduced mod 2^24 by the import kernel).
  *
  * Randomness: the "spawn stream" (oracle/g2048_oracle.h has the same text and is the checker)
  *    word(seed, t, board, slot) = Philox4x32-10(ctr = (t_lo, t_hi, board, slot >> 2),
@@ -75,6 +82,12 @@ typedef struct {
     uint8_t *illegal;        /* [n] info['illegal_move'] (:79-81,:93) */
     uint8_t *highest;        /* [n] log2(info['highest']) (:97), of the board BEFORE an auto-reset */
     uint8_t *terminal_boards;/* [n][16] written only where terminated: the episode's last board */
+    void *obs;               /* [n][16][4][4] of obs_dtype: stack(self.Matrix), the first element of the tuple step()
+                              * returns (:100, :17-32), written by the step launch itself (no second kernel, no re-read of
+                              * the records): the one-hot of the board AFTER the step -- with auto_reset, of the fresh board
+                              * where the episode ended (the terminal one is terminal_boards), as a VecEnv returns it.
+                              * 16-byte aligned.  NULL = not wanted */
+    int32_t obs_dtype;       /* G2048_OBS_*; ignored when obs is NULL */
 } g2048_step_io;
 
 /* Episode statistics since create/seed. */
@@ -129,14 +142,14 @@ int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *s
 
 /* k consecutive g2048_step launches without returning to the caller.  Buffers of step j are the
  * io pointers advanced by j * stride elements (stride = 0 reuses the same buffers, stride = n
- * walks [k][n] rollout buffers). */
+ * walks [k][n] rollout buffers; an element of obs is one board's whole [16][4][4] observation). */
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream);
 
 /* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /
  * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead
  * of 46).  For action sequences that are known in advance (replays, scripted or tree-search rollouts);
- * a policy that needs every observation uses g2048_step / g2048_rollout.  terminal_boards must be
+ * a policy that needs every observation uses g2048_step / g2048_rollout.  terminal_boards and obs must be
  * NULL; not available in numpy-RNG mode. */
 int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                         void *stream);
@@ -256,11 +269,17 @@ int g2048_comm_unique_id(uint8_t id[G2048_COMM_ID_BYTES]);
 int g2048_comm_create(int world, int rank, const uint8_t id[G2048_COMM_ID_BYTES], int device, g2048_comm **out);
 int g2048_comm_destroy(g2048_comm *c);
 int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, void *stream);
-/* One process driving several GPUs: engines[r] on distinct devices with equal board counts; a
- * communicator set is built with ncclCommInitAll, every engine's last returns are all-gathered into
- * outs[r][n_engines * n] (device memory on engine r's device) on streams[r] (NULL = null streams), the
- * streams are synchronised and the communicators destroyed. */
-int g2048_allgather_returns_local(g2048_engine *const *engines, int n_engines, int32_t *const *outs,
+/* One process driving several GPUs.  g2048_comm_local_create builds the communicator set ONCE (ncclCommInitAll over
+ * `devices`, distinct; hundreds of milliseconds on 8 GPUs -- not something to pay per rollout) and
+ * g2048_allgather_returns_local reuses it: engines[r] must live on devices[r] and hold equal board counts; every
+ * engine's last returns are all-gathered into outs[r][n_devices * n] (device memory on devices[r]).  The export
+ * kernels and the grouped ncclAllGather are ENQUEUED on streams[r] (NULL array = null streams); nothing is
+ * synchronised: outs[r] is complete when streams[r] reaches that point. */
+typedef struct g2048_comm_local g2048_comm_local;
+#define G2048_COMM_LOCAL_MAX 64
+int g2048_comm_local_create(const int *devices, int n_devices, g2048_comm_local **out);
+int g2048_comm_local_destroy(g2048_comm_local *c);
+int g2048_allgather_returns_local(g2048_comm_local *c, g2048_engine *const *engines, int32_t *const *outs,
                                   void *const *streams);
 
 #ifdef __cplusplus

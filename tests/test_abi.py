@@ -43,7 +43,7 @@ def test_abi_version(lib):
 
 def test_struct_layouts():
     from gym2048_amd import _lib
-    assert C.sizeof(_lib.StepIO) == 56      # 7 x 8 bytes (int32 padded)
+    assert C.sizeof(_lib.StepIO) == 72      # 9 x 8 bytes (the two int32 dtype codes padded)
     assert C.sizeof(_lib.Stats) == 168     # 40 + uint32 highest_hist[32]
 
 

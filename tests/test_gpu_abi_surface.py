@@ -171,7 +171,7 @@ def test_canonicalize_vs_reference_table_and_oracle(torch_cuda):
 def test_collective_behind_the_c_abi_one_rank(torch_cuda):
     """g2048_comm_* / g2048_allgather_returns with RCCL loaded by the library itself: a one-rank communicator
     (the degenerate case a 1-GPU box can run) gathers the engine's returns; the single-process multi-engine
-    form with one engine does the same."""
+    form (persistent g2048_comm_local) with one engine does the same, repeatedly."""
     torch = torch_cuda
     from gym2048_amd import _lib
     from gym2048_amd.batched import Batched2048
@@ -192,11 +192,23 @@ def test_collective_behind_the_c_abi_one_rank(torch_cuda):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
     _lib.check(lib.g2048_comm_destroy(comm))
-    out2 = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    # single-process form: the communicator set is built ONCE and reused by every rollout's all-gather
+    local = C.c_void_p()
+    devices = (C.c_int * 1)(0)
+    _lib.check(lib.g2048_comm_local_create(devices, 1, C.byref(local)))
     engines = (C.c_void_p * 1)(eng._h)
-    outs = (C.c_void_p * 1)(out2.data_ptr())
-    _lib.check(lib.g2048_allgather_returns_local(engines, 1, outs, None))
-    assert np.array_equal(out2.cpu().numpy(), want)
+    streams = (C.c_void_p * 1)(stream.value)
+    for rep in range(3):
+        out2 = torch.zeros(n, dtype=torch.int32, device=eng.device)
+        outs = (C.c_void_p * 1)(out2.data_ptr())
+        _lib.check(lib.g2048_allgather_returns_local(local, engines, outs, streams))   # enqueued, not synchronised
+        torch.cuda.synchronize()
+        assert np.array_equal(out2.cpu().numpy(), want)
+        eng.rollout(8)
+        want = eng.get_last_scores()
+    _lib.check(lib.g2048_comm_local_destroy(local))
+    dup = (C.c_int * 2)(0, 0)
+    assert lib.g2048_comm_local_create(dup, 2, C.byref(local)) != 0         # one communicator per device
     assert lib.g2048_comm_create(2, 5, ident, 0, C.byref(comm)) != 0     # rank out of range
 
 

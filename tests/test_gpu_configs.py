@@ -4,6 +4,7 @@
   configs[2]  2^20 boards, random policy            -> test_full_batch_2p20_random_policy_vs_oracle (full batch)
               + a legality-aware greedy policy (deep states: big tiles, full-board endings)
   configs[3]  shards of one batch on several ranks  -> test_two_rank_hip_shards_allgather (2 processes, gloo, cuda:0)
+              + the N > 1 code path of bench.py over RCCL -> test_bench_forced_dist_runs_the_rccl_path (one-rank group)
   configs[4]  2^20 boards driving a torch policy    -> test_policy_loop_2p20_zero_copy_vs_oracle
 """
 import os
@@ -169,6 +170,35 @@ def test_two_rank_hip_shards_allgather(torch_cuda, tmp_path):
     assert int(got["last_max"]) == st["last_score_max"] and got["hist"].tolist() == st["highest_hist"]
     from gym2048_amd.batched import parse_stats
     assert parse_stats(whole.episode_stats_device()) == st                  # async device struct == sync host struct
+
+
+@pytest.mark.parametrize("gather", ["summary", "full"])
+def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
+    """bench.py's N > 1 code path over the REAL backend on the one GPU there is: G2048_BENCH_FORCE_DIST=1 makes a
+    one-rank `nccl` (= RCCL) process group, so init_process_group("nccl", device_id=...), the all-gather of a
+    device tensor enqueued behind the K launches, the NCCL barrier and the max-reduction all execute.  The line
+    must carry the timing split the scaling analysis needs, and the fixed cost the collective adds to the driver's
+    20-launch train must stay small (DESIGN.md section 6 derives the predicted 8-GPU efficiency from it)."""
+    import json
+    env = dict(os.environ, G2048_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(31000 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-extras",
+                          "--gather", gather], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and "forced_dist" in line["config"]
+    assert line["value"] > 1e10 and line["episodes_finished"] > 0
+    t = line["timing"]
+    assert t["launch_train_us"] > 0 and t["collective_us"] > 0
+    print(f"forced-dist ({gather}): launch train {t['launch_train_us']:.1f} us, collective {t['collective_us']:.1f} us, "
+          f"host tail {t['host_tail_us']:.1f} us, value {line['value']:.3e}")
+    # a loose regression bound (the measured figures are in DESIGN.md section 6): the once-per-rollout exchange must not
+    # cost more than the 20 launches it follows
+    assert t["collective_us"] < t["launch_train_us"], t
+    if gather == "summary":
+        assert line["global_returns"]["episodes"] == line["episodes_finished"]
 
 
 def test_more_than_4_gib_of_records(torch_cuda):
