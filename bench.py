@@ -443,10 +443,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             extras["python_port_steps_per_s_1core"] = python_port_rate()
 
-    if rank == 0:
-        print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION
+        # on the GPU boxes), which a pipe would otherwise flush at exit -- after Python's own buffer
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:  # pragma: no cover
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

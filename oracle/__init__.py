@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libg2048_oracle.so")
+# G2048_ORACLE_LIB: an alternative build of the same sources (the sanitizer build of `make -C oracle asan`)
+_SO = os.environ.get("G2048_ORACLE_LIB") or os.path.join(_HERE, "libg2048_oracle.so")
 _lib = None
 
 
@@ -28,6 +29,8 @@ class _Batch(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("G2048_ORACLE_LIB"):
+        return _SO                                   # a pre-built alternative library: never rebuilt here
     src = [os.path.join(_HERE, f) for f in ("g2048_oracle.c", "g2048_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libg2048_oracle.so"], stdout=subprocess.DEVNULL)

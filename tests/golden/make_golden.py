@@ -313,7 +313,8 @@ def gen_training_data_fixtures(report):
     for name, add_returns in (("transitions_ref.csv", False), ("transitions_ref_returns.csv", True)):
         path = os.path.join(HERE, name)
         td.export_csv(path, add_returns=add_returns)
-        report.append(f"{name}: {os.path.getsize(path)} bytes (written by the reference's training_data.export_csv)")
+        report.append(f"{name}: {os.path.getsize(path)} bytes sha256[:16]={hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]} "
+                      f"(written by the reference's training_data.export_csv)")
     base = dict(x=td.get_x().copy(), action=td.get_y_digit().copy(), reward=td.get_reward().copy(),
                 next_x=td.get_next_x().copy(), done=td.get_done().copy(),
                 returns=td.get_discounted_return().copy())
@@ -629,6 +630,21 @@ def gen_eval_table(ref, rng):
     return out
 
 
+def load_npz(path):
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def content_hash(d) -> str:
+    """sha256[:16] over the fixture's content: sorted keys, dtype, shape and raw bytes of every array."""
+    h = hashlib.sha256()
+    for k in sorted(d):
+        a = np.ascontiguousarray(d[k])
+        h.update(f"{k}|{a.dtype.str}|{a.shape}|".encode())
+        h.update(a.tobytes())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--validate-steps", type=int, default=1_000_000)
@@ -641,10 +657,15 @@ def main():
     report = []
 
     def save(name, d):
+        # The fixture is only rewritten when its CONTENT changed (a zip archive carries timestamps, so its bytes
+        # differ from run to run); the report lists a hash of the content -- keys, dtypes, shapes, array bytes --
+        # which tests/test_oracle_golden.py::test_validation_report_covers_every_fixture recomputes.
         path = os.path.join(HERE, name)
-        np.savez_compressed(path, **d)
-        h = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
-        report.append(f"{name}: {os.path.getsize(path)} bytes sha256[:16]={h}")
+        d = {k: np.asarray(v) for k, v in d.items()}
+        h = content_hash(d)
+        if not (os.path.exists(path) and content_hash(load_npz(path)) == h):
+            np.savez_compressed(path, **d)
+        report.append(f"{name}: {len(d)} arrays, {sum(v.nbytes for v in d.values())} bytes of data, content sha256[:16]={h}")
 
     if args.only_data:
         save("training_data_fixture.npz", gen_training_data_fixtures(report))
@@ -685,6 +706,10 @@ def main():
     save("eval_table.npz", gen_eval_table(ref, np.random.default_rng(10)))
     validate(ref, args.validate_steps, report)
     time_reference(ref, report)
+    import datetime
+    oracle_c = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "g2048_oracle.c")
+    report.append(f"generated {datetime.date.today().isoformat()} with numpy {np.__version__}; oracle/g2048_oracle.c "
+                  f"sha256[:16]={hashlib.sha256(open(oracle_c, 'rb').read()).hexdigest()[:16]}")
     with open(os.path.join(HERE, "VALIDATION.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
     print("\n".join(report))

@@ -187,7 +187,9 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-extras",
                           "--gather", gather], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), f"the JSON line must be the last line of stdout, got: {lines[-3:]}"
+    line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 20 and "forced_dist" in line["config"]
     assert line["value"] > 1e10 and line["episodes_finished"] > 0
     t = line["timing"]

@@ -219,3 +219,35 @@ def test_oracle_rewards_match_the_reference_add_rewards_table(oracle_lib):
             legal = oracle_lib.g2048o_move(M, int(a), 1, C.byref(sc))
             assert (float(sc.value) if legal else irw) == want
     assert (t["rewards_minus1"] == -1.0).sum() >= 10         # the table contains illegal moves
+
+
+def test_validation_report_covers_every_fixture():
+    """Provenance: tests/golden/VALIDATION.txt (written by make_golden.py in the build container, where the
+    reference can be imported) lists EVERY fixture with a hash of its content, and the committed fixtures still
+    have exactly that content; the report also carries the reference-vs-oracle cross-validation line."""
+    import glob
+    import hashlib
+    import os
+    import re
+    from conftest import GOLDEN
+
+    def content_hash(path):              # = make_golden.content_hash
+        h = hashlib.sha256()
+        with np.load(path, allow_pickle=False) as z:
+            for k in sorted(z.files):
+                a = np.ascontiguousarray(z[k])
+                h.update(f"{k}|{a.dtype.str}|{a.shape}|".encode())
+                h.update(a.tobytes())
+        return h.hexdigest()[:16]
+
+    report = open(os.path.join(GOLDEN, "VALIDATION.txt")).read()
+    listed = dict(re.findall(r"^(\S+\.npz): .*content sha256\[:16\]=([0-9a-f]{16})$", report, flags=re.M))
+    on_disk = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    assert sorted(listed) == on_disk, "VALIDATION.txt must list every .npz fixture (re-run tests/golden/make_golden.py)"
+    for name in on_disk:
+        assert content_hash(os.path.join(GOLDEN, name)) == listed[name], name
+    for name, digest in re.findall(r"^(\S+\.csv): \d+ bytes sha256\[:16\]=([0-9a-f]{16})", report, flags=re.M):
+        assert hashlib.sha256(open(os.path.join(GOLDEN, name), "rb").read()).hexdigest()[:16] == digest, name
+    m = re.search(r"validated (\d+) env-steps .* of the imported reference against the C oracle and the Python oracle: "
+                  r"all .* identical", report)
+    assert m and int(m.group(1)) >= 900_000
