@@ -5,11 +5,12 @@ same GPU, zero host copies.
     python bench_policy.py [--boards 1048576] [--steps 20] [--chunk 131072] [--dtype float16]
 
 Loop per env-step (everything stays in HBM, everything on torch's current HIP stream):
-  1. ``Batched2048.observe_onehot(out=obs)``  -- onehot kernel writes (N,16,4,4) into a torch tensor;
-  2. policy forward in chunks: the trunk of ``ppo_train.py:36-62`` (conv3x3 16->64, BN, ReLU, 4 x the
-     residual block of ``model.py:10-25``) + the action head SB3 adds on the flattened 1024 features
+  1. policy forward in chunks on the observation tensor: the trunk of ``ppo_train.py:36-62`` (conv3x3 16->64, BN,
+     ReLU, 4 x the residual block of ``model.py:10-25``) + the action head SB3 adds on the flattened 1024 features
      (``net_arch=[]``, ``ppo_train.py:131-133``) -> greedy ``argmax`` (int64), random-init weights;
-  3. ``Batched2048.step(actions)`` reads the int64 action tensor through its data_ptr.
+  2. ``Batched2048.step(actions, obs=obs)``: ONE launch reads the int64 action tensor through its data_ptr, plays
+     the step and writes the next (N,16,4,4) observation into the torch tensor (game2048_env.py:100).
+The first observation comes from ``observe_onehot`` after the reset.
 
 This is a consumer-side measurement (the policy is PyTorch-ROCm/MIOpen, out of scope of this repo);
 it reports env-steps/s of the whole loop and the fraction of the time spent in the env kernels.
@@ -68,18 +69,19 @@ def run(boards=1 << 20, steps=20, warmup=3, chunk=1 << 17, dtype="float16") -> d
     obs = torch.empty((n, 16, 4, 4), dtype=dt, device=dev)
     actions = torch.empty(n, dtype=torch.int64, device=dev)
 
+    eng.observe_onehot(out=obs)                    # observation of the reset; every later one comes from step()
+
     def one_step(timers=None):
         t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), \
             torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0[0].record()
-        eng.observe_onehot(out=obs)
         t0[1].record()
         with torch.no_grad():
             for lo in range(0, n, args.chunk):
                 logits = policy(obs[lo:lo + args.chunk].contiguous(memory_format=torch.channels_last))
                 actions[lo:lo + args.chunk] = logits.argmax(dim=1)
         t0[2].record()
-        eng.step(actions, want_info=False)
+        eng.step(actions, want_info=False, obs=obs)
         t0[3].record()
         if timers is not None:
             timers.append(t0)
@@ -102,8 +104,9 @@ def run(boards=1 << 20, steps=20, warmup=3, chunk=1 << 17, dtype="float16") -> d
         "metric": "env-steps/sec with a ppo_train.py-shaped policy in the loop (BASELINE configs[4])",
         "value": n * args.steps / wall, "unit": "env-steps/s", "boards": n, "steps": args.steps,
         "policy_dtype": args.dtype, "policy_chunk": args.chunk,
-        "ms_per_step": {"onehot": onehot_ms, "policy_forward_argmax": policy_ms, "env_step": step_ms,
+        "ms_per_step": {"policy_forward_argmax": policy_ms, "env_step_with_observation": step_ms,
                         "wall": wall * 1e3 / args.steps},
+        "launches_per_env_step": 1,
         "env_fraction_of_loop": (onehot_ms + step_ms) / (onehot_ms + policy_ms + step_ms),
         "host_copies": 0, "episodes_finished": int(stats["episodes"]),
         "mean_last_episode_score": stats["mean_last_score"], "max_tile": 1 << int(stats["max_exp"])})

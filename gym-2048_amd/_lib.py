@@ -32,6 +32,21 @@ class StepIO(C.Structure):
         ("terminal_boards", C.c_void_p),
         ("obs", C.c_void_p),
         ("obs_dtype", C.c_int32),
+        ("boards_out", C.c_void_p),
+    ]
+
+
+class HostIO(C.Structure):
+    """g2048_host_io (include/g2048.h): host addresses of the engine's pinned, device-mapped I/O block."""
+    _fields_ = [
+        ("actions", C.c_void_p),
+        ("reward", C.c_void_p),
+        ("terminated", C.c_void_p),
+        ("illegal", C.c_void_p),
+        ("highest", C.c_void_p),
+        ("boards", C.c_void_p),
+        ("terminal_boards", C.c_void_p),
+        ("scores", C.c_void_p),
     ]
 
 
@@ -66,6 +81,9 @@ SIGNATURES = {
     "g2048_set_max_tile": (C.c_int, [_E, C.c_int]),
     "g2048_reset": (C.c_int, [_E, C.c_int, _u32, C.c_void_p, _S]),
     "g2048_step": (C.c_int, [_E, C.POINTER(StepIO), C.c_int, _S]),
+    "g2048_host_io_map": (C.c_int, [_E, C.POINTER(HostIO)]),
+    "g2048_step_host": (C.c_int, [_E, C.c_int, _S]),
+    "g2048_fetch_host": (C.c_int, [_E, _S]),
     "g2048_rollout": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_fused": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_random": (C.c_int, [_E, _u32, _S]),

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import G2048Error, StepIO, Stats, check
+from ._lib import G2048Error, HostIO, StepIO, Stats, check
 
 _ACTION_DTYPES = {torch.uint8: _lib.ACT_U8, torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}
 _OBS_DTYPES = {torch.uint8: _lib.OBS_U8, torch.float16: _lib.OBS_F16, torch.float32: _lib.OBS_F32}
@@ -419,6 +419,45 @@ class Batched2048:
         self._fresh = bool(state.get("fresh", False))
         self.rng_mode = state.get("rng_mode", "philox")
 
+    # ------------------------------------------------------------------ host-resident I/O
+    def host_io(self) -> dict:
+        """numpy views of the engine's pinned, device-mapped host block (``g2048_host_io``): ``actions`` int64[n]
+        (IN), ``reward`` float32[n], ``terminated`` / ``illegal`` / ``highest`` uint8[n], ``boards`` and
+        ``terminal_boards`` uint8[n,4,4], ``scores`` int32[n].  ``step_host`` / ``fetch_host`` fill them in place."""
+        if getattr(self, "_host_io", None) is None:
+            raw = HostIO()
+            check(self._lib.g2048_host_io_map(self._h, C.byref(raw)))
+            n = self.n_envs
+
+            def view(ptr, ctype, shape):
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=shape)
+
+            self._host_io = dict(
+                actions=view(raw.actions, C.c_int64, (n,)), reward=view(raw.reward, C.c_float, (n,)),
+                terminated=view(raw.terminated, C.c_uint8, (n,)), illegal=view(raw.illegal, C.c_uint8, (n,)),
+                highest=view(raw.highest, C.c_uint8, (n,)), boards=view(raw.boards, C.c_uint8, (n, 4, 4)),
+                terminal_boards=view(raw.terminal_boards, C.c_uint8, (n, 4, 4)), scores=view(raw.scores, C.c_int32, (n,)))
+            # pre-bound call for the latency-critical single-env path
+            self._step_host_fn, self._fetch_host_fn = self._lib.g2048_step_host, self._lib.g2048_fetch_host
+        return self._host_io
+
+    def step_host(self, auto_reset: bool = True) -> dict:
+        """game2048_env.py:76-100 with host arrays: the caller has written ``host_io()['actions']``; ONE launch reads
+        them across the bus and writes every output into the views, and the call returns when they are there (the
+        host polls a completion word: no staging copy, no stream synchronisation).  Returns the same dict."""
+        io = self.host_io()
+        rc = self._step_host_fn(self._h, 1 if auto_reset else 0, self._stream())
+        if rc:
+            check(rc)
+        self._fresh = False
+        return io
+
+    def fetch_host(self) -> dict:
+        """Current boards and scores into the host views (after reset / set_boards / add_tile / move)."""
+        io = self.host_io()
+        check(self._fetch_host_fn(self._h, self._stream()))
+        return io
+
     # ------------------------------------------------------------------ numpy facade (used by the
     # single-env and VecEnv adapters; tests replace this object by an oracle-backed fake)
     def _host_staging(self):
@@ -429,7 +468,7 @@ class Batched2048:
             n = self.n_envs
             up = lambda x: (x + 15) & ~15  # noqa: E731
             off, sizes = {}, (("reward", 4 * n), ("terminated", n), ("illegal", n), ("highest", n),
-                              ("terminal_boards", 16 * n), ("boards", 16 * n))
+                              ("terminal_boards", 16 * n), ("boards", 16 * n), ("obs", 256 * n))
             pos = 0
             for name, size in sizes:
                 off[name] = (pos, size)
@@ -441,32 +480,47 @@ class Batched2048:
                 act_host=torch.zeros(n, dtype=torch.int64).pin_memory(),
                 act_dev=torch.zeros(n, dtype=torch.int64, device=self.device),
                 reward=view["reward"].view(torch.float32), terminated=view["terminated"], illegal=view["illegal"],
-                highest=view["highest"], terminal_boards=view["terminal_boards"].view(n, 16), boards=view["boards"])
+                highest=view["highest"], terminal_boards=view["terminal_boards"].view(n, 16), boards=view["boards"],
+                obs=view["obs"].view(n, 16, 4, 4), small=off["obs"][0])
         return self._stage
 
-    def step_numpy(self, actions, auto_reset: bool = True) -> dict:
-        """Step with host actions and bring every per-step output back in ONE device-to-host copy
-        (reward, terminated, illegal, highest, terminal boards, boards after the step) through pinned memory."""
+    def step_numpy(self, actions, auto_reset: bool = True, obs_dtype=None) -> dict:
+        """Step with host actions and bring every per-step output back in ONE device-to-host copy (reward,
+        terminated, illegal, highest, terminal boards, boards after the step) through pinned memory.  ONE launch:
+        the plain boards are the kernel's ``boards_out`` and, with ``obs_dtype``, the uint8 one-hot observation is
+        its fused ``obs`` output, both written into the same packed buffer (``obs`` in the result; an integer type
+        wider than uint8 is widened on the device and copied separately)."""
         st = self._host_staging()
         n = self.n_envs
         st["act_host"].numpy()[:] = np.asarray(actions).reshape(n)
         st["act_dev"].copy_(st["act_host"], non_blocking=True)
-        io = self._io(st["act_dev"], st["reward"], st["terminated"], st["illegal"], st["highest"], st["terminal_boards"])
+        io = self._io(st["act_dev"], st["reward"], st["terminated"], st["illegal"], st["highest"], st["terminal_boards"],
+                      st["obs"] if obs_dtype is not None else None)
+        io.boards_out = st["boards"].data_ptr()
         check(self._lib.g2048_step(self._h, C.byref(io), int(auto_reset), self._stream()))
         self._fresh = False
-        check(self._lib.g2048_get_boards(self._h, st["boards"].data_ptr(), self._stream()))
-        st["host"].copy_(st["dev"], non_blocking=True)
+        want_u8_obs = obs_dtype is not None and np.dtype(obs_dtype) == np.uint8
+        nbytes = st["dev"].numel() if want_u8_obs else st["small"]           # the observation rides along only as uint8
+        st["host"][:nbytes].copy_(st["dev"][:nbytes], non_blocking=True)
+        wide = None
+        if obs_dtype is not None and not want_u8_obs:
+            wide = st["obs"].to(getattr(torch, np.dtype(obs_dtype).name)).cpu().numpy()
         torch.cuda.current_stream(self.device).synchronize()
         raw = st["host"].numpy()
         part = lambda k: raw[st["off"][k][0]: st["off"][k][0] + st["off"][k][1]]  # noqa: E731
         # keep the engine's public per-step views coherent with what was just computed
         self.reward, self.terminated, self.illegal, self.highest = st["reward"], st["terminated"], st["illegal"], st["highest"]
         self.terminal_boards = st["terminal_boards"]
-        return dict(reward=part("reward").view(np.float32).copy(),
-                    terminated=part("terminated").astype(bool), illegal=part("illegal").astype(bool),
-                    highest=part("highest").copy(),
-                    terminal_boards=part("terminal_boards").reshape(n, 4, 4).copy(),
-                    boards=part("boards").reshape(n, 4, 4).copy())
+        out = dict(reward=part("reward").view(np.float32).copy(),
+                   terminated=part("terminated").astype(bool), illegal=part("illegal").astype(bool),
+                   highest=part("highest").copy(),
+                   terminal_boards=part("terminal_boards").reshape(n, 4, 4).copy(),
+                   boards=part("boards").reshape(n, 4, 4).copy())
+        if want_u8_obs:
+            out["obs"] = part("obs").reshape(n, 16, 4, 4).copy()
+        elif wide is not None:
+            out["obs"] = wide
+        return out
 
     def onehot_numpy(self, dtype=np.uint8) -> np.ndarray:
         """Host copy of the one-hot observation in ``dtype``.  The kernel writes uint8; a wider integer type is

@@ -6,10 +6,12 @@
 
 #include <rccl/rccl.h> // declarations only: librccl is dlopen()ed by the first g2048_comm_* call
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <mutex>
 #include <new>
 
@@ -52,6 +54,12 @@ struct g2048_engine {
     g2048::StatsOut *stats_dev = nullptr;
     unsigned long long *stats_partials = nullptr; // stage-1 output of the statistics reduction
     void *scratch = nullptr; // staging for host-side get/set of boards and scores (16 B per board), lazily
+    // host-resident I/O (g2048_host_io_map): one block of pinned, device-mapped, coherent host memory
+    void *host_base = nullptr;
+    g2048_host_io host_io{};          // host addresses handed to the caller
+    g2048_host_io host_io_dev{};      // the same arrays as the device sees them
+    unsigned long long *done_host = nullptr, *done_dev = nullptr; // completion word, polled by the host
+    unsigned long long done_count = 0;
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
 };
@@ -81,6 +89,7 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
         a.terminal_boards = reinterpret_cast<uint4 *>(io->terminal_boards);
         a.obs = io->obs;
         a.obs_dtype = static_cast<uint32_t>(io->obs_dtype);
+        a.boards_out = reinterpret_cast<uint4 *>(io->boards_out);
     }
     a.n = static_cast<uint32_t>(e->n);
     a.board_offset = static_cast<uint32_t>(e->board_offset);
@@ -116,9 +125,10 @@ int check_io(const g2048_step_io *io)
         return fail(G2048_ERR_INVALID, "actions is NULL but action_dtype is %d", io->action_dtype);
     // the kernels use natural-width loads and stores
     if ((reinterpret_cast<uintptr_t>(io->actions) & (action_size(io->action_dtype) ? action_size(io->action_dtype) - 1 : 0)) ||
-        (reinterpret_cast<uintptr_t>(io->reward) & 3u) || (reinterpret_cast<uintptr_t>(io->terminal_boards) & 15u))
+        (reinterpret_cast<uintptr_t>(io->reward) & 3u) || (reinterpret_cast<uintptr_t>(io->terminal_boards) & 15u) ||
+        (reinterpret_cast<uintptr_t>(io->boards_out) & 15u))
         return fail(G2048_ERR_INVALID, "misaligned buffer: actions need their element size, reward 4 bytes, "
-                                       "terminal_boards 16 bytes");
+                                       "terminal_boards and boards_out 16 bytes");
     if (io->obs) {
         if (io->obs_dtype < G2048_OBS_U8 || io->obs_dtype > G2048_OBS_F32)
             return fail(G2048_ERR_INVALID, "unknown obs_dtype %d", io->obs_dtype);
@@ -210,6 +220,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipFree(e->scratch);
         if (e->returns)
             (void)hipFree(e->returns);
+        if (e->host_base)
+            (void)hipHostFree(e->host_base);
         if (e->stats_partials)
             (void)hipFree(e->stats_partials);
         err = hipFree(e->slab);
@@ -297,10 +309,13 @@ int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *s
     e->t += 1;
     e->fresh = 0;
     const g2048::StepArgs a = make_args(e, io, auto_reset);
-    if (e->st.rng)
+    if (e->st.rng) {
         G2048_HIP(g2048::launch_step_numpy(a, io->action_dtype, static_cast<hipStream_t>(stream)));
-    else
+        if (a.boards_out) // this mode's resets run behind the step kernel: the plain boards come from the export kernel
+            G2048_HIP(g2048::launch_export_boards(e->st.boards, a.n, a.boards_out, static_cast<hipStream_t>(stream)));
+    } else {
         G2048_HIP(g2048::launch_step(a, io->action_dtype, static_cast<hipStream_t>(stream)));
+    }
     return G2048_OK;
 }
 
@@ -323,13 +338,17 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         if (s.highest) s.highest = io->highest + off;
         if (s.terminal_boards) s.terminal_boards = io->terminal_boards + off * 16;
         if (s.obs) s.obs = static_cast<char *>(io->obs) + off * obs_board_bytes(io->obs_dtype);
+        if (s.boards_out) s.boards_out = io->boards_out + off * 16;
         e->t += 1;
         e->fresh = 0;
         const g2048::StepArgs a = make_args(e, &s, auto_reset);
-        if (e->st.rng)
+        if (e->st.rng) {
             G2048_HIP(g2048::launch_step_numpy(a, s.action_dtype, static_cast<hipStream_t>(stream)));
-        else
+            if (a.boards_out)
+                G2048_HIP(g2048::launch_export_boards(e->st.boards, a.n, a.boards_out, static_cast<hipStream_t>(stream)));
+        } else {
             G2048_HIP(g2048::launch_step(a, s.action_dtype, static_cast<hipStream_t>(stream)));
+        }
     }
     return G2048_OK;
 }
@@ -341,8 +360,8 @@ int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *
         return fail(G2048_ERR_INVALID, "engine is NULL");
     if (int rc = check_io(io))
         return rc;
-    if (io->terminal_boards || io->obs)
-        return fail(G2048_ERR_INVALID, "g2048_rollout_fused writes neither terminal_boards nor obs");
+    if (io->terminal_boards || io->obs || io->boards_out)
+        return fail(G2048_ERR_INVALID, "g2048_rollout_fused writes neither terminal_boards, boards_out nor obs");
     if (e->st.rng)
         return fail(G2048_ERR_INVALID, "g2048_rollout_fused draws from the spawn stream; not available in numpy-RNG mode");
     if (k_steps == 0)
@@ -466,6 +485,132 @@ static int copy_in(g2048_engine *e, void *dst, const void *src, size_t bytes, vo
     G2048_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
     G2048_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return G2048_OK;
+}
+
+// ------------------------------------------------------------------------- host-resident I/O
+static int ensure_host_io(g2048_engine *e)
+{
+    if (e->host_base)
+        return G2048_OK;
+    const size_t n = e->n;
+    auto up = [](size_t x) { return (x + 63) & ~static_cast<size_t>(63); };
+    const size_t off_act = 0, off_rew = up(off_act + 8 * n), off_term = up(off_rew + 4 * n), off_ill = up(off_term + n),
+                 off_high = up(off_ill + n), off_boards = up(off_high + n), off_tb = up(off_boards + 16 * n),
+                 off_sc = up(off_tb + 16 * n), off_done = up(off_sc + 4 * n), bytes = off_done + 64;
+    void *host = nullptr, *dev = nullptr;
+    hipError_t err = hipHostMalloc(&host, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (err != hipSuccess)
+        return fail(G2048_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    err = hipHostGetDevicePointer(&dev, host, 0);
+    if (err != hipSuccess) {
+        (void)hipHostFree(host);
+        return fail(G2048_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(err));
+    }
+    std::memset(host, 0, bytes);
+    auto fill = [&](g2048_host_io &io, char *b) {
+        io.actions = reinterpret_cast<int64_t *>(b + off_act);
+        io.reward = reinterpret_cast<float *>(b + off_rew);
+        io.terminated = reinterpret_cast<uint8_t *>(b + off_term);
+        io.illegal = reinterpret_cast<uint8_t *>(b + off_ill);
+        io.highest = reinterpret_cast<uint8_t *>(b + off_high);
+        io.boards = reinterpret_cast<uint8_t *>(b + off_boards);
+        io.terminal_boards = reinterpret_cast<uint8_t *>(b + off_tb);
+        io.scores = reinterpret_cast<int32_t *>(b + off_sc);
+    };
+    fill(e->host_io, static_cast<char *>(host));
+    fill(e->host_io_dev, static_cast<char *>(dev));
+    e->done_host = reinterpret_cast<unsigned long long *>(static_cast<char *>(host) + off_done);
+    e->done_dev = reinterpret_cast<unsigned long long *>(static_cast<char *>(dev) + off_done);
+    e->host_base = host;
+    return G2048_OK;
+}
+
+// Poll the completion word (written by the device with system-scope release) until it shows `want`.
+static int wait_done(g2048_engine *e, unsigned long long want, hipStream_t s)
+{
+    using clock = std::chrono::steady_clock;
+    clock::time_point last_check{};
+    bool armed = false;
+    for (uint64_t spins = 0;; ++spins) {
+        if (__atomic_load_n(e->done_host, __ATOMIC_ACQUIRE) == want)
+            return G2048_OK;
+        _mm_pause();
+        if ((spins & 0xfffffu) == 0xfffffu) { // every ~million polls: is the stream still alive?
+            const clock::time_point now = clock::now();
+            if (!armed) {
+                armed = true;
+                last_check = now;
+            } else if (now - last_check > std::chrono::seconds(2)) {
+                last_check = now;
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) // everything on the stream has finished: the word must be there
+                    return __atomic_load_n(e->done_host, __ATOMIC_ACQUIRE) == want
+                               ? G2048_OK
+                               : fail(G2048_ERR_HIP, "the device finished without publishing the completion word");
+                if (q != hipErrorNotReady)
+                    return fail(G2048_ERR_HIP, "stream failed while waiting for a host-resident step: %s", hipGetErrorString(q));
+            }
+        }
+    }
+}
+
+int g2048_host_io_map(g2048_engine *e, g2048_host_io *out)
+{
+    if (!e || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    if (int rc = ensure_host_io(e))
+        return rc;
+    *out = e->host_io;
+    return G2048_OK;
+}
+
+int g2048_step_host(g2048_engine *e, int auto_reset, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (!e->host_base)
+        return fail(G2048_ERR_INVALID, "call g2048_host_io_map first (the actions are read from its buffer)");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const g2048_host_io &d = e->host_io_dev;
+    g2048_step_io io{};
+    io.actions = d.actions;
+    io.action_dtype = G2048_ACT_I64;
+    io.reward = d.reward;
+    io.terminated = d.terminated;
+    io.illegal = d.illegal;
+    io.highest = d.highest;
+    io.terminal_boards = d.terminal_boards;
+    io.boards_out = d.boards;
+    e->t += 1;
+    e->fresh = 0;
+    g2048::StepArgs a = make_args(e, &io, auto_reset);
+    const unsigned long long want = ++e->done_count;
+    if (e->st.rng) { // numpy-RNG mode: step (+ compacted resets), then boards + scores + the completion word
+        a.boards_out = nullptr;
+        G2048_HIP(g2048::launch_step_numpy(a, io.action_dtype, s));
+        G2048_HIP(g2048::launch_fetch(e->st.boards, a.n, reinterpret_cast<uint4 *>(d.boards), d.scores, e->done_dev, want, s));
+    } else {
+        a.done_seq = e->done_dev;
+        a.done_value = want;
+        G2048_HIP(g2048::launch_step(a, io.action_dtype, s));
+    }
+    return wait_done(e, want, s);
+}
+
+int g2048_fetch_host(g2048_engine *e, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (!e->host_base)
+        return fail(G2048_ERR_INVALID, "call g2048_host_io_map first");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned long long want = ++e->done_count;
+    G2048_HIP(g2048::launch_fetch(e->st.boards, static_cast<uint32_t>(e->n), reinterpret_cast<uint4 *>(e->host_io_dev.boards),
+                                  e->host_io_dev.scores, e->done_dev, want, s));
+    return wait_done(e, want, s);
 }
 
 // Is p device-accessible memory of this process (hipMalloc / torch tensor)?  Plain host memory is not

@@ -39,6 +39,9 @@ struct StepArgs {
     uint8_t *illegal;
     uint8_t *highest;
     uint4 *terminal_boards;
+    uint4 *boards_out;  // [n][16] plain cells of the board AFTER the step (and its auto-reset), or NULL
+    unsigned long long *done_seq; // host-visible completion word (mapped pinned memory) or NULL: a launch of ONE block writes
+    unsigned long long done_value; //   done_value there after all of its outputs (system-scope release); see g2048_step_host
     void *obs;          // [n][16][4][4] one-hot observation of the board AFTER the step (and its auto-reset), or NULL
     uint32_t obs_dtype; // G2048_OBS_*
     uint32_t n;
@@ -92,6 +95,10 @@ hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *score
 hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, hipStream_t s);
 hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s);
 hipError_t launch_export_last_scores(const DeviceState &st, uint32_t n, int32_t *out, hipStream_t s);
+// host-resident I/O: boards + scores of the current state in one launch; the completion word (see StepArgs::done_seq)
+hipError_t launch_fetch(const uint4 *records, uint32_t n, uint4 *cells_out, int32_t *scores_out, unsigned long long *done_seq,
+                        unsigned long long done_value, hipStream_t s);
+hipError_t launch_signal(unsigned long long *done_seq, unsigned long long done_value, hipStream_t s);
 hipError_t launch_canonicalize(uint4 *boards, uint4 *next_boards, uint8_t *actions, uint32_t n, uint8_t *sym_out,
                                hipStream_t s);
 

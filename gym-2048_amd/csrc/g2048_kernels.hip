@@ -247,6 +247,28 @@ __device__ __forceinline__ void emit_onehot(uint4 *wave_recs, const Board &rec, 
     }
 }
 
+// ------------------------------------------------------------------- host-visible completion
+// g2048_step_host / g2048_fetch_host: the outputs of a launch live in mapped, coherent pinned HOST memory and the host
+// polls one word instead of calling into the runtime (hipStreamSynchronize costs ~5 us more per call than a poll,
+// tools/ubench/host_latency.hip).  A ONE-block launch publishes the word itself: every wave makes its stores visible
+// at system scope, the block meets, one lane stores the value with release semantics.  Larger launches are followed
+// by signal_kernel on the same stream (the kernel boundary orders it behind the outputs).
+__device__ __forceinline__ void signal_done(unsigned long long *done_seq, unsigned long long value)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && gridDim.x == 1)
+        __hip_atomic_store(done_seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(64) signal_kernel(unsigned long long *done_seq, unsigned long long value)
+{
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(done_seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
@@ -272,6 +294,9 @@ struct StepTail {
     uint32_t auto_reset;
     void *obs;          // HAS_OBS kernels only
     uint32_t obs_dtype;
+    uint4 *boards_out;  // !STD kernels only
+    unsigned long long *done_seq;
+    unsigned long long done_value;
 };
 
 // STD: the standard configuration -- reward and terminated present, no illegal / highest / terminal_boards, no
@@ -339,10 +364,14 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
             __builtin_nontemporal_store(static_cast<uint8_t>(o.legal ? 0 : 1), p.illegal + i);
         if (p.highest)
             __builtin_nontemporal_store(static_cast<uint8_t>(top), p.highest + i);
+        if (!STD && tail.boards_out)
+            store_board(tail.boards_out, i, record_cells(rec));
     }
     flush_episode_counts(counters, episodes, illegal_ends);
     if constexpr (HAS_OBS)
         emit_onehot<FULL>(s_recs + (threadIdx.x & ~63u), rec, tail.obs, tail.obs_dtype, i_raw & ~63u, n);
+    if (!STD && tail.done_seq)
+        signal_done(tail.done_seq, tail.done_value);
 }
 
 // ------------------------------------------------------------------------- fused rollout
@@ -1082,7 +1111,7 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     const dim3 g = grid_for(a.n), b(kBlock);
     const bool full = a.n % kBlock == 0;
     const StepTail tail{a.terminated, a.st.last_record, a.illegal, a.highest, a.terminal_boards, a.illegal_reward, a.max_exp,
-                        a.auto_reset, a.obs, a.obs_dtype};
+                        a.auto_reset, a.obs, a.obs_dtype, a.boards_out, a.done_seq, a.done_value};
 #define G2048_STEP_LAUNCH(ACT, FULL, STD, OBS)                                                                          \
     hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,         \
                        a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail)
@@ -1097,7 +1126,8 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
         else                                                                                                            \
             G2048_STEP_LAUNCH(ACT, FULL, false, false);                                                                 \
     } while (0)
-    const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0;
+    const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0 &&
+                          !a.boards_out && !a.done_seq;
     switch (action_dtype * 2 + (full ? 1 : 0)) {
     case 0: G2048_STEP(0, false); break;
     case 1: G2048_STEP(0, true); break;
@@ -1111,6 +1141,8 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
 #undef G2048_STEP_LAUNCH
     default: return hipErrorInvalidValue;
     }
+    if (a.done_seq && g.x > 1) // a one-block launch has published the word itself
+        hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, a.done_seq, a.done_value);
     return hipGetLastError();
 }
 
@@ -1331,6 +1363,36 @@ hipError_t launch_export_last_scores(const DeviceState &st, uint32_t n, int32_t 
     if (n == 0)
         return hipSuccess;
     hipLaunchKernelGGL(export_last_scores_kernel, grid_for(n), dim3(kBlock), 0, s, st.last_record, n, out);
+    return hipGetLastError();
+}
+
+// get_board + self.score of every board in one launch, for the host-resident path
+__global__ void __launch_bounds__(kBlock) fetch_kernel(const uint4 *records, uint32_t n, uint4 *cells_out, int32_t *scores_out,
+                                                       unsigned long long *done_seq, unsigned long long done_value)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const Board raw = load_board(records, i);
+        store_board(cells_out, i, record_cells(raw));
+        scores_out[i] = static_cast<int32_t>(record_score(raw));
+    }
+    if (done_seq)
+        signal_done(done_seq, done_value);
+}
+
+hipError_t launch_fetch(const uint4 *records, uint32_t n, uint4 *cells_out, int32_t *scores_out, unsigned long long *done_seq,
+                        unsigned long long done_value, hipStream_t s)
+{
+    const dim3 g = grid_for(n);
+    hipLaunchKernelGGL(fetch_kernel, g, dim3(kBlock), 0, s, records, n, cells_out, scores_out, done_seq, done_value);
+    if (done_seq && g.x > 1)
+        hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, done_seq, done_value);
+    return hipGetLastError();
+}
+
+hipError_t launch_signal(unsigned long long *done_seq, unsigned long long done_value, hipStream_t s)
+{
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, done_seq, done_value);
     return hipGetLastError();
 }
 

@@ -34,10 +34,20 @@ class IllegalMove(Exception):
 
 def stack(flat, layers=15):
     """game2048_env.py:17-32: (4,4) tile values -> (layers+1,4,4) one-hot (host arrays; the batched
-    device version is ``Batched2048.observe_onehot``)."""
+    device version is ``Batched2048.observe_onehot`` / the ``obs`` output of ``step``)."""
     flat = np.asarray(flat)
     targets = np.concatenate([[0], 2 ** (np.arange(layers, dtype=np.int64) + 1)])
     return (flat[np.newaxis, :, :] == targets[:, np.newaxis, np.newaxis]).astype(int)
+
+
+_CHANNELS = np.arange(16, dtype=np.uint8).reshape(16, 1, 1)
+_TILE_VALUES = np.array([0] + [1 << e for e in range(1, 32)], dtype=np.int64)   # exponent -> tile value
+
+
+def _stack_exp(cells):
+    """``stack()`` of a uint8 (4,4) board of EXPONENTS: channel c = (exponent == c); a tile >= 2^16 matches no
+    channel, like the reference (game2048_env.py:17-32).  Same dtype and shape as the reference's result."""
+    return (cells == _CHANNELS).astype(int)
 
 
 class _Space:
@@ -88,6 +98,7 @@ class Game2048Env(_env_base()):
             from .batched import Batched2048
             engine = Batched2048(1, device=device, seed=int.from_bytes(os.urandom(7), "little"), rng=rng)
         self._eng = engine
+        self._io = engine.host_io()   # numpy views of the engine's pinned host block (actions in, outputs back)
         self._scratch = None    # a one-board engine for shift(), created on first use
         self._scratch_factory = getattr(engine, "scratch_factory", None)
         self._slot = 0          # next spawn slot of the current transaction
@@ -111,20 +122,25 @@ class Game2048Env(_env_base()):
 
     # ------------------------------------------------------------------ gym interface
     def step(self, action):
-        """game2048_env.py:76-100."""
-        res = self._eng.step_numpy(np.array([int(action)]), auto_reset=False)
-        illegal = bool(res["illegal"][0])
+        """game2048_env.py:76-100.  ONE call into the library: the action goes into the engine's pinned host block,
+        the step kernel reads it and writes reward / flags / highest / the 16 cell bytes back into the same block, and
+        ``stack()`` of those bytes is built here on the host -- no one-hot kernel, no staging copy for a single board."""
+        io = self._io
+        io["actions"][0] = int(action)
+        self._eng.step_host(False)
+        illegal = bool(io["illegal"][0])
         info = {"illegal_move": illegal}
         if illegal:
             reward = self.illegal_move_reward
             self._slot = 0
         else:
-            reward = float(res["reward"][0])
+            reward = float(io["reward"][0])
             self.score += reward
             self._slot = 1
-        board = _exp_to_values(res["boards"][0])          # came back with the step's single copy
-        info["highest"] = np.max(board)                   # :97
-        return stack(board), reward, bool(res["terminated"][0]), False, info
+        cells = io["boards"][0]
+        info["highest"] = _TILE_VALUES[io["highest"][0]]   # :97 np.max(self.Matrix), an np.int64
+        self._cells = cells
+        return _stack_exp(cells), reward, bool(io["terminated"][0]), False, info
 
     def reset(self, seed=None, options=None):
         """game2048_env.py:102-111."""
@@ -153,12 +169,12 @@ class Game2048Env(_env_base()):
 
     # ------------------------------------------------------------------ board access
     def _obs(self):
-        return self._eng.onehot_numpy(np.int64)[0]
+        return _stack_exp(self._eng.fetch_host()["boards"][0])
 
     @property
     def Matrix(self):
         """game2048_env.py:104 -- int64 (4,4) tile values (a host copy of the device board)."""
-        return _exp_to_values(self._eng.get_boards()[0])
+        return _TILE_VALUES[self._eng.fetch_host()["boards"][0]]
 
     @Matrix.setter
     def Matrix(self, new_board):
@@ -208,12 +224,17 @@ class Game2048Env(_env_base()):
         """game2048_env.py:243-260 (runs as a left move of a SCRATCH engine's board holding ``row``; the env's
         own board is not touched)."""
         if self._scratch is None:
-            self._scratch = type(self._eng)(1) if self._scratch_factory is None else self._scratch_factory()
+            if self._scratch_factory is not None:
+                self._scratch = self._scratch_factory()
+            elif hasattr(self._eng, "device_index"):   # on the env's own device
+                self._scratch = type(self._eng)(1, device=self._eng.device_index)
+            else:
+                self._scratch = type(self._eng)(1)
         board = np.zeros((1, 4, 4), np.uint8)
         board[0, 0] = _values_to_exp(row)
         self._scratch.set_boards(board)
         score, _ = self._scratch.move_numpy(np.array([3]), trial=False)
-        out = _exp_to_values(self._scratch.get_boards()[0, 0])
+        out = _TILE_VALUES[self._scratch.fetch_host()["boards"][0, 0]]
         return [int(v) for v in out], int(score[0])
 
     def isend(self):

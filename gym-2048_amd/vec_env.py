@@ -46,12 +46,12 @@ class Vec2048(_vec_env_base()):
             engine = Batched2048(n_envs, device=device, seed=seed, board_offset=board_offset, rng=rng)
         self.engine = engine
         self.action_space, self.observation_space = make_spaces()
-        if _vec_env_base() is not object:
-            super().__init__(int(n_envs), self.observation_space, self.action_space)
+        self.render_mode = None             # before VecEnv.__init__: SB3 reads it through get_attr("render_mode")
         self.num_envs = int(n_envs)
         self.obs_dtype = np.dtype(obs_dtype)
-        self.render_mode = None
         self._illegal_move_reward = float(illegal_move_reward)
+        if _vec_env_base() is not object:
+            super().__init__(int(n_envs), self.observation_space, self.action_space)
         self.engine.set_illegal_move_reward(self._illegal_move_reward)
         self.engine.set_max_tile(max_tile)
         self._actions = None
@@ -78,10 +78,10 @@ class Vec2048(_vec_env_base()):
         self._actions = np.asarray(actions).reshape(self.num_envs)
 
     def step_wait(self):
-        res = self.engine.step_numpy(self._actions, auto_reset=True)
+        res = self.engine.step_numpy(self._actions, auto_reset=True, obs_dtype=self.obs_dtype)   # ONE launch, obs included
         dones = np.asarray(res["terminated"], dtype=bool)
         rewards = np.asarray(res["reward"], dtype=np.float32)
-        obs = self._obs()
+        obs = res["obs"]
         self._ep_return += rewards
         self._ep_length += 1
         infos = [_EMPTY_INFO] * self.num_envs

@@ -88,7 +88,26 @@ typedef struct {
                               * where the episode ended (the terminal one is terminal_boards), as a VecEnv returns it.
                               * 16-byte aligned.  NULL = not wanted */
     int32_t obs_dtype;       /* G2048_OBS_*; ignored when obs is NULL */
+    uint8_t *boards_out;     /* [n][16] plain cell exponents of the board AFTER the step (self.Matrix, :104; after the
+                              * auto-reset where it applies); 16-byte aligned.  NULL = not wanted */
 } g2048_step_io;
+
+/* Host-resident I/O for callers that hold HOST arrays -- the reference's own calling convention: one Python int in,
+ * numpy out (game2048_env.py:76-100).  The engine owns one block of pinned, device-mapped, coherent host memory;
+ * g2048_step_host's kernel reads the actions from it and writes every output straight into it across the bus, and
+ * the call returns when they are visible (the host polls a completion word the device publishes last: no staging
+ * copy, no stream-synchronisation call -- about 10 us per call for a handful of boards).  Pointers are HOST
+ * addresses, valid until g2048_destroy. */
+typedef struct {
+    int64_t *actions;         /* [n] IN: fill before g2048_step_host (low two bits used) */
+    float *reward;            /* [n] */
+    uint8_t *terminated;      /* [n] */
+    uint8_t *illegal;         /* [n] */
+    uint8_t *highest;         /* [n] exponent of the highest tile (before an auto-reset) */
+    uint8_t *boards;          /* [n][16] cells after the step / at g2048_fetch_host */
+    uint8_t *terminal_boards; /* [n][16], rows valid where terminated */
+    int32_t *scores;          /* [n] self.score: written by g2048_fetch_host (and by g2048_step_host in numpy-RNG mode) */
+} g2048_host_io;
 
 /* Episode statistics since create/seed. */
 typedef struct {
@@ -140,6 +159,14 @@ int g2048_reset(g2048_engine *e, int new_transaction, uint32_t first_slot, const
  * launch (slots 1,2 after a legal move, 0,1 after an illegal one). */
 int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *stream);
 
+/* The host-resident forms (see g2048_host_io).  g2048_host_io_map allocates the block on first use and returns its
+ * arrays.  g2048_step_host = g2048_step with actions from / all outputs to those arrays (int64 actions, reward,
+ * terminated, illegal, highest, terminal_boards, boards); it BLOCKS until the outputs are in host memory.
+ * g2048_fetch_host brings the current boards and scores there (after reset / set_boards / add_tile / move). */
+int g2048_host_io_map(g2048_engine *e, g2048_host_io *out);
+int g2048_step_host(g2048_engine *e, int auto_reset, void *stream);
+int g2048_fetch_host(g2048_engine *e, void *stream);
+
 /* k consecutive g2048_step launches without returning to the caller.  Buffers of step j are the
  * io pointers advanced by j * stride elements (stride = 0 reuses the same buffers, stride = n
  * walks [k][n] rollout buffers; an element of obs is one board's whole [16][4][4] observation). */
@@ -149,8 +176,8 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
 /* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /
  * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead
  * of 46).  For action sequences that are known in advance (replays, scripted or tree-search rollouts);
- * a policy that needs every observation uses g2048_step / g2048_rollout.  terminal_boards and obs must be
- * NULL; not available in numpy-RNG mode. */
+ * a policy that needs every observation uses g2048_step / g2048_rollout.  terminal_boards, boards_out and obs
+ * must be NULL; not available in numpy-RNG mode. */
 int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                         void *stream);
 

@@ -50,15 +50,42 @@ class OracleEngine:
     def observe_onehot(self, dtype=np.float32):
         return self.ob.onehot().astype(dtype)
 
-    def step_numpy(self, actions, auto_reset=True):
+    def step_numpy(self, actions, auto_reset=True, obs_dtype=None):
         if self.rng_mode == "numpy":
             self.ob.step_numpy(np.asarray(actions) & 3, auto_reset=auto_reset)
         else:
             self.ob.step(np.asarray(actions) & 3, auto_reset=auto_reset)
         o = self.ob
-        return dict(reward=o.reward.copy(), terminated=o.terminated.astype(bool), illegal=o.illegal.astype(bool),
-                    highest=o.highest.copy(), terminal_boards=o.terminal_boards.reshape(-1, 4, 4).copy(),
-                    boards=o.boards.reshape(-1, 4, 4).copy())
+        out = dict(reward=o.reward.copy(), terminated=o.terminated.astype(bool), illegal=o.illegal.astype(bool),
+                   highest=o.highest.copy(), terminal_boards=o.terminal_boards.reshape(-1, 4, 4).copy(),
+                   boards=o.boards.reshape(-1, 4, 4).copy())
+        if obs_dtype is not None:
+            out["obs"] = o.onehot().astype(obs_dtype)
+        return out
+
+    # host-resident I/O (Batched2048.host_io / step_host / fetch_host)
+    def host_io(self):
+        if not hasattr(self, "_io"):
+            n = self.n_envs
+            self._io = dict(actions=np.zeros(n, np.int64), reward=np.zeros(n, np.float32), terminated=np.zeros(n, np.uint8),
+                            illegal=np.zeros(n, np.uint8), highest=np.zeros(n, np.uint8),
+                            boards=np.zeros((n, 4, 4), np.uint8), terminal_boards=np.zeros((n, 4, 4), np.uint8),
+                            scores=np.zeros(n, np.int32))
+        return self._io
+
+    def step_host(self, auto_reset=True):
+        io = self.host_io()
+        res = self.step_numpy(io["actions"], auto_reset=auto_reset)
+        for k in ("reward", "terminated", "illegal", "highest", "boards", "terminal_boards"):
+            io[k][...] = res[k]
+        io["scores"][...] = self.ob.score
+        return io
+
+    def fetch_host(self):
+        io = self.host_io()
+        io["boards"][...] = self.ob.boards.reshape(-1, 4, 4)
+        io["scores"][...] = self.ob.score
+        return io
 
     # observations / state
     def get_boards(self):

