@@ -343,13 +343,24 @@ def main():
         eng.rollout_random(kf)
         torch.cuda.synchronize()
         extras["fused_rollout_steps_per_s"] = kf * B / (time.perf_counter() - t1)
-        # (a2) the SAME rollout as the timed region (same actions, same [K][B] outputs) as ONE fused launch
+        # (a2) per-step I/O as in the timed region (action[j][i] in, reward[j][i] / terminated[j][i] out) but as ONE
+        #      fused launch of 256 steps with the boards in registers (g2048_rollout_fused; own [256][B] buffers)
         try:
-            kf2 = min(K, 256)
-            t1 = time.perf_counter()
-            eng.rollout(actions[:kf2], reward=reward[:kf2], terminated=terminated[:kf2], fused=True)
+            kf2 = 256
+            fa = eng.random_actions(kf2)
+            fr = torch.zeros((kf2, B), dtype=torch.float32, device=dev)
+            ft = torch.zeros((kf2, B), dtype=torch.uint8, device=dev)
+            fplan = eng.prepare_rollout(fa, reward=fr, terminated=ft, fused=True)
+            fplan.run()
             torch.cuda.synchronize()
-            extras["fused_rollout_with_io_steps_per_s"] = kf2 * B / (time.perf_counter() - t1)
+            fa = eng.random_actions(kf2, out=fa)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fplan.run()
+            e1.record()
+            torch.cuda.synchronize()
+            extras["fused_rollout_with_io_steps_per_s"] = kf2 * B / (e0.elapsed_time(e1) * 1e-3)
+            del fa, fr, ft, fplan
         except Exception as exc:  # pragma: no cover
             extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
         # (a3) the env-step INCLUDING the observation the reference's step() returns (stack(), game2048_env.py:100):

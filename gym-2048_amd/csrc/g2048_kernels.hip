@@ -195,6 +195,15 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 __device__ __forceinline__ uint32_t eq_flags(uint32_t cells, uint32_t splat) { return (kHigh1 - (cells ^ splat)) & kHigh1; }
 __device__ __forceinline__ uint32_t eq_ones(uint32_t cells, uint32_t splat) { return ((kHigh1 - (cells ^ splat)) >> 7) & 0x01010101u; }
 
+// Occupancy of the kernels that write observations is CAPPED at 3 workgroups (12 wavefronts) per CU by launching
+// them with this much unused dynamic LDS (6 KiB static + 42 KiB = 48 KiB per workgroup of the CU's 160 KiB).  The
+// kernel is bound by DRAM writes, and every resident wavefront owns its own 16-64 KiB output region: with all 32
+// wave slots of a CU filled the chip writes into 8 192 regions at once (128 MiB of open write window at u8) and the
+// memory system runs at 5.1-5.7 TB/s; with 12 it reaches 5.7-6.2 TB/s -- -10 % time at 2^20 boards, -7 % at 2^24
+// (tools/ubench/r3_probe.hip part B, profiles/r03_d_probe_*.txt: 2 / 3 / 4 workgroups per CU all beat the uncapped
+// launch; the arithmetic needs a sixth of the issue slots, so nothing is lost on the compute side).
+constexpr uint32_t kObsOccupancyPad = 42u * 1024u;
+
 template <bool FULL>
 __device__ __forceinline__ void emit_onehot(uint4 *wave_recs, const Board &rec, void *obs, uint32_t obs_dtype,
                                             uint32_t wave_first, uint32_t n)
@@ -1113,8 +1122,8 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     const StepTail tail{a.terminated, a.st.last_record, a.illegal, a.highest, a.terminal_boards, a.illegal_reward, a.max_exp,
                         a.auto_reset, a.obs, a.obs_dtype, a.boards_out, a.done_seq, a.done_value};
 #define G2048_STEP_LAUNCH(ACT, FULL, STD, OBS)                                                                          \
-    hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, 0, s, a.st.boards, a.actions, a.st.ep_counters,         \
-                       a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail)
+    hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, (OBS) ? kObsOccupancyPad : 0u, s, a.st.boards, a.actions, \
+                       a.st.ep_counters, a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail)
 #define G2048_STEP(ACT, FULL)                                                                                           \
     do {                                                                                                                \
         if (standard && a.obs)                                                                                          \
