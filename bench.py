@@ -228,7 +228,7 @@ def main():
         if args.gather == "full":
             local = eng.last_scores(out=returns_buf)     # int32[B] returns, from the terminal records (one kernel)
             return allgather_returns(local.cpu() if host_gather else local, shard)
-        local = eng.episode_stats_device(out=stats_buf)
+        local = eng.episode_stats_device(out=stats_buf, returns_only=True)
         return allgather_stats(local.cpu() if host_gather else local)
 
     # ---- device warm-up on a scratch engine (every rank): not steps of the benchmarked engine, whose own

@@ -102,6 +102,7 @@ SIGNATURES = {
     "g2048_last_records_ptr": (C.c_void_p, [_E]),
     "g2048_episode_stats": (C.c_int, [_E, C.POINTER(Stats), _S]),
     "g2048_episode_stats_async": (C.c_int, [_E, C.c_void_p, _S]),
+    "g2048_returns_summary_async": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_set_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_numpy_rng": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_seed_numpy": (C.c_int, [_E, _u64, _S]),

@@ -391,16 +391,18 @@ class Batched2048:
         check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
         return parse_stats(bytes(st))
 
-    def episode_stats_device(self, out=None) -> torch.Tensor:
+    def episode_stats_device(self, out=None, returns_only: bool = False) -> torch.Tensor:
         """The same reduction as ``episode_stats`` left ON THE DEVICE: a ``uint8 [sizeof(g2048_stats)]`` tensor
         holding the C struct, enqueued on the current stream without a host sync (what a multi-GPU job
-        all-gathers once per rollout; decode with ``parse_stats``)."""
+        all-gathers once per rollout; decode with ``parse_stats``).  ``returns_only``: only the episode counters and
+        the returns of the boards' last episodes (``max_exp`` / ``highest_hist`` zero) -- the live boards are not read."""
         nbytes = C.sizeof(Stats)
         if out is None:
             out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         if out.dtype != torch.uint8 or out.numel() != nbytes or not out.is_contiguous() or out.device != self.device:
             raise ValueError(f"out must be a contiguous uint8 [{nbytes}] tensor on the engine's device")
-        check(self._lib.g2048_episode_stats_async(self._h, out.data_ptr(), self._stream()))
+        fn = self._lib.g2048_returns_summary_async if returns_only else self._lib.g2048_episode_stats_async
+        check(fn(self._h, out.data_ptr(), self._stream()))
         return out
 
     # ------------------------------------------------------------------ checkpoint / resume

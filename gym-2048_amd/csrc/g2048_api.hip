@@ -785,7 +785,7 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, e->stats_dev, s));
+    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, e->stats_dev, false, s));
     g2048::StatsOut h{};
     G2048_HIP(hipMemcpyAsync(&h, e->stats_dev, sizeof h, hipMemcpyDeviceToHost, s));
     G2048_HIP(hipStreamSynchronize(s));
@@ -800,17 +800,27 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     return G2048_OK;
 }
 
-int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, void *stream)
+static int stats_async(const g2048_engine *e, g2048_stats *device_out, bool returns_only, void *stream)
 {
     static_assert(sizeof(g2048_stats) == sizeof(g2048::StatsOut), "g2048_stats and the kernel's StatsOut must share one layout");
     if (!e || !device_out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (!is_device_ptr(device_out))
-        return fail(G2048_ERR_INVALID, "g2048_episode_stats_async needs a DEVICE buffer (use g2048_episode_stats for a host struct)");
+        return fail(G2048_ERR_INVALID, "the asynchronous statistics need a DEVICE buffer (use g2048_episode_stats for a host struct)");
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, reinterpret_cast<g2048::StatsOut *>(device_out),
-                                  static_cast<hipStream_t>(stream)));
+                                  returns_only, static_cast<hipStream_t>(stream)));
     return G2048_OK;
+}
+
+int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, void *stream)
+{
+    return stats_async(e, device_out, false, stream);
+}
+
+int g2048_returns_summary_async(const g2048_engine *e, g2048_stats *device_out, void *stream)
+{
+    return stats_async(e, device_out, true, stream);
 }
 
 // numpy-RNG mode state: the five PCG64 planes plus the per-wavefront lists of finished boards, one allocation

@@ -87,7 +87,8 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
 // partials: kStatsPartialWords uint64 of device scratch (stage 1 -> stage 2; field-major, one column per block)
 constexpr uint32_t kStatsBlocks = 2048;
 constexpr uint32_t kStatsPartialWords = (6 + 32) * kStatsBlocks;
-hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, hipStream_t s);
+hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, bool returns_only,
+                        hipStream_t s);
 // record <-> plain views (cells uint8[n][16], scores int32[n]); device pointers
 hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s);
 hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s);

@@ -993,6 +993,10 @@ __global__ void __launch_bounds__(kBlock) canonicalize_kernel(uint4 *boards, uin
 constexpr int kStatsFields = 6 + 32; // episodes, illegal_ends, last_count, last_score_sum, last_score_max, max_exp, hist[32]
 static_assert(kStatsFields * kStatsBlocks == kStatsPartialWords, "partials buffer size");
 
+// WITH_BOARDS = false is the RETURNS-ONLY flavour (what a multi-GPU job all-gathers once per rollout): counters and
+// terminal records only -- the live boards are not read (half the traffic) and the 32 ballots per 64 boards of the
+// histogram are not executed; max_exp and highest_hist[] come out as zero.
+template <bool WITH_BOARDS>
 __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
                                                        unsigned long long *partials)
 {
@@ -1001,9 +1005,9 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
     __shared__ unsigned int s_hist[32];
     unsigned long long episodes = 0, illegal = 0, score_sum = 0, count = 0;
     unsigned int max_score = 0, max_exp = 0;
-    uint32_t hist[32];
+    uint32_t hist[WITH_BOARDS ? 32 : 1];
 #pragma unroll
-    for (int b = 0; b < 32; ++b)
+    for (int b = 0; b < (WITH_BOARDS ? 32 : 1); ++b)
         hist[b] = 0u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < 32u)
@@ -1021,8 +1025,10 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
         uint32_t h = 0xffu;
         if (i < n) {
             const Board last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
-            h = highest(record_cells(load_board_nt(st.boards, static_cast<uint32_t>(i))));
-            max_exp = max(max_exp, h);
+            if constexpr (WITH_BOARDS) {
+                h = highest(record_cells(load_board_nt(st.boards, static_cast<uint32_t>(i))));
+                max_exp = max(max_exp, h);
+            }
             if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
                 const unsigned int sc = record_score(last);
                 count += 1;
@@ -1030,17 +1036,21 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
                 max_score = max(max_score, sc);
             }
         }
+        if constexpr (WITH_BOARDS) {
 #pragma unroll
-        for (uint32_t b = 0; b < 32u; ++b)
-            hist[b] += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(h == b)));
+            for (uint32_t b = 0; b < 32u; ++b)
+                hist[b] += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(h == b)));
+        }
     }
     s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_cnt[tid] = count;
     s_max[tid] = max_score; s_exp[tid] = max_exp;
-    if (lane == 0u) {
+    if constexpr (WITH_BOARDS) {
+        if (lane == 0u) {
 #pragma unroll
-        for (int b = 0; b < 32; ++b)
-            if (hist[b] != 0u)
-                atomicAdd(&s_hist[b], hist[b]);
+            for (int b = 0; b < 32; ++b)
+                if (hist[b] != 0u)
+                    atomicAdd(&s_hist[b], hist[b]);
+        }
     }
     __syncthreads();
     for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
@@ -1063,16 +1073,24 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
         mine[4 * kStatsBlocks] = s_max[0];
         mine[5 * kStatsBlocks] = s_exp[0];
     }
-    if (tid < 32u)
+    if (WITH_BOARDS && tid < 32u)
         mine[(6u + tid) * kStatsBlocks] = s_hist[tid];
 }
 
 // block f: field f of every partial -> the matching member of *out (fields 4 and 5 are maxima, the rest sums)
+// (the returns-only flavour launches the first six blocks only; block 5 then clears max_exp and the histogram)
 __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long long *partials, uint32_t n_partials,
                                                              StatsOut *out)
 {
     __shared__ unsigned long long s_v[kBlock];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    if (gridDim.x == 6u && f == 5u) { // returns-only: nothing was counted for these
+        if (tid < 32u)
+            out->highest_hist[tid] = 0u;
+        if (tid == 0)
+            out->max_exp = 0u;
+        return;
+    }
     const bool is_max = f == 4u || f == 5u;
     unsigned long long v = 0;
     for (uint32_t q = tid; q < n_partials; q += kBlock) {
@@ -1315,15 +1333,21 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
     return hipGetLastError();
 }
 
-hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, hipStream_t s)
+hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, bool returns_only,
+                        hipStream_t s)
 {
     uint32_t blocks = grid_for(n).x;
     if (blocks > kStatsBlocks)
         blocks = kStatsBlocks;
     if (blocks == 0)
         blocks = 1; // n == 0: one block writes an all-zero partial
-    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
-    hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out);
+    if (returns_only) {
+        hipLaunchKernelGGL(stats_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
+        hipLaunchKernelGGL(stats_merge_kernel, dim3(6), dim3(kBlock), 0, s, partials, blocks, dev_out);
+    } else {
+        hipLaunchKernelGGL(stats_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
+        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out);
+    }
     return hipGetLastError();
 }
 
