@@ -10,4 +10,7 @@ cp $S/kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp $S/traffic.json profiles/${T}_traffic.json
 cp $S/traffic.json profiles/traffic_latest.json
 cp $S/bench_under_rocprof.json profiles/${T}_bench_under_rocprof.json
+[ -f $S/kernel_stats_extras.csv ] && cp $S/kernel_stats_extras.csv profiles/${T}_kernel_stats_extras.csv
+[ -f $S/summary_obs_kernel.txt ] && cp $S/summary_obs_kernel.txt profiles/${T}_obs_kernel_summary.txt
+[ -f $S/bench_extras_under_rocprof.json ] && cp $S/bench_extras_under_rocprof.json profiles/${T}_bench_extras_under_rocprof.json
 python -c "import bench, json; t = json.load(open('profiles/traffic_latest.json')); print('profile', t['profile'], 'csrc', t['csrc_sha16'], 'current', bench.csrc_hash())"

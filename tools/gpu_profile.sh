@@ -21,6 +21,15 @@ rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_DRAM_32B -d $O/pmc_rd32 -o r -- $BE
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_WRITE_DRAM_32B -d $O/pmc_wr32 -o r -- $BENCH > $O/pmc_wr32.log 2>&1
 python tools/rocpd_summary.py $O/stats/r_results.db $O/pmc_sq1/r_results.db $O/pmc_sq2/r_results.db $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_tcc/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > $O/summary.txt 2>&1
 python tools/rocpd_summary.py --traffic-json $O/traffic.json --profile-tag $TAG --csrc-hash $(python -c "import bench; print(bench.csrc_hash())") $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > /dev/null 2>&1
+# the same with the extras (the observation-writing step kernel, fused rollouts, the 2^24 streaming run, ...):
+# kernel-trace statistics of every kernel, and the HBM traffic counters of the step kernel that writes observations
+BENCHX="python bench.py --steps 200 --warmup 20 --cpu-seconds 1 $*"
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/statsx -o r -- $BENCHX > $O/statsx.log 2>&1
+cp $O/statsx/r_kernel_stats.csv $O/kernel_stats_extras.csv 2>/dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcx_fetch -o r -- $BENCHX > $O/pmcx_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmcx_write -o r -- $BENCHX > $O/pmcx_write.log 2>&1
+python tools/rocpd_summary.py --kernel "step_kernel<1, true, true, true>" $O/statsx/r_results.db $O/pmcx_fetch/r_results.db $O/pmcx_write/r_results.db > $O/summary_obs_kernel.txt 2>&1
+grep -h '"metric"' $O/statsx.log > $O/bench_extras_under_rocprof.json
 grep -h '"metric"' $O/stats.log > $O/bench_under_rocprof.json
 rm -rf $O/*/r_results.db   # keep the merged gpurun_out small; the summary is what gets committed
 cat $O/summary.txt
