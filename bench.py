@@ -313,7 +313,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_provenance": traffic_prov,
-                     "kernel": "g2048::step_kernel<1, true, true>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                     "kernel": "g2048::step_kernel<1, true, true, false>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us,
                      "note": (f"the {working_set_mib:.0f} MiB of board records touched per launch sit in the 256 MiB "
                               "Infinity Cache at this batch size, so this is a cache-resident figure; "
@@ -454,19 +454,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             extras["python_port_steps_per_s_1core"] = python_port_rate()
 
+    # The JSON line must be the LAST thing on stdout.  RCCL prints a version banner through C stdio, which a pipe only
+    # flushes at exit -- after Python's own buffer -- and under torch.distributed.run every rank shares one stdout: so
+    # every rank flushes its C stdio now, the ranks meet, and only then rank 0 prints.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:  # pragma: no cover
+        pass
+    sys.stdout.flush()
+    if dist_on:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION
-        # on the GPU boxes), which a pipe would otherwise flush at exit -- after Python's own buffer
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:  # pragma: no cover
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
-
-
-if __name__ == "__main__":
-    main()

@@ -1,7 +1,8 @@
 // client.cpp -- TEST: a caller of libg2048_hip.so that knows nothing but include/g2048.h (no Python, no torch).
 // It plays the benchmark's random-policy rollout through the C ABI with raw hipMalloc'ed I/O buffers and checks
 // every board, reward, flag, score and episodic return against the CPU oracle (oracle/g2048_oracle.h, linked
-// here as the checker).  Built by __graft_entry__.build() with hipcc; run by tests/test_gpu_abi_surface.py.
+// here as the checker); then the observation-returning step and the host-resident step, the same way.
+// Built by __graft_entry__.build() with hipcc; run by tests/test_gpu_abi_surface.py.
 //   usage: client [n_boards] [steps] [seed] [board_offset]
 #include <hip/hip_runtime.h>
 
@@ -91,8 +92,57 @@ int main(int argc, char **argv)
                     (unsigned long long)st.illegal_ends, (unsigned long long)episodes, (unsigned long long)illegal_ends);
         return 1;
     }
+    // ---- phase 2: the step that returns its observation (g2048_step_io.obs, one launch) and the host-resident step
+    //      (g2048_host_io_map / g2048_step_host: no hipMemcpy, no stream synchronisation by the caller), 12 more steps
+    uint8_t *d_obs;
+    HIP_OK(hipMalloc(&d_obs, n * 256));
+    std::vector<uint8_t> obs(n * 256), want(n * 256);
+    g2048_host_io hio{};
+    G_OK(g2048_host_io_map(eng, &hio));
+    for (uint32_t j = 0; j < 12; ++j) {
+        const uint64_t t = 1 + steps + j;
+        std::vector<uint8_t> a(n);
+        for (uint64_t i = 0; i < n; ++i)
+            a[i] = g2048o_random_action(seed, t, static_cast<uint32_t>(offset + i));
+        b.actions = a.data();
+        if (j % 2 == 0) { // device buffers + fused uint8 observation
+            HIP_OK(hipMemcpy(d_actions, a.data(), n, hipMemcpyHostToDevice));
+            g2048_step_io s2{};
+            s2.actions = d_actions;
+            s2.action_dtype = G2048_ACT_U8;
+            s2.reward = d_reward;
+            s2.terminated = d_term;
+            s2.obs = d_obs;
+            s2.obs_dtype = G2048_OBS_U8;
+            G_OK(g2048_step(eng, &s2, 1, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            HIP_OK(hipMemcpy(obs.data(), d_obs, n * 256, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(reward.data(), d_reward, n * sizeof(float), hipMemcpyDeviceToHost));
+            g2048o_step_batch(&b, n, seed, t, offset, -1.0f, 0, 1, 0);
+            g2048o_onehot_batch(o_boards.data(), n, want.data());
+            if (std::memcmp(obs.data(), want.data(), n * 256) || std::memcmp(reward.data(), o_reward.data(), n * sizeof(float))) {
+                std::printf("FAIL fused observation / reward at extra step %u\n", j);
+                return 1;
+            }
+        } else {          // host-resident I/O
+            for (uint64_t i = 0; i < n; ++i)
+                hio.actions[i] = a[i];
+            G_OK(g2048_step_host(eng, 1, stream));
+            g2048o_step_batch(&b, n, seed, t, offset, -1.0f, 0, 1, 0);
+            if (std::memcmp(hio.boards, o_boards.data(), n * 16) || std::memcmp(hio.reward, o_reward.data(), n * sizeof(float)) ||
+                std::memcmp(hio.terminated, o_term.data(), n) || std::memcmp(hio.illegal, o_ill.data(), n)) {
+                std::printf("FAIL host-resident step at extra step %u\n", j);
+                return 1;
+            }
+        }
+    }
+    G_OK(g2048_fetch_host(eng, stream));
+    if (std::memcmp(hio.boards, o_boards.data(), n * 16) || std::memcmp(hio.scores, o_score.data(), n * 4)) {
+        std::printf("FAIL g2048_fetch_host boards / scores\n");
+        return 1;
+    }
     G_OK(g2048_destroy(eng));
-    std::printf("OK %llu boards x %u steps through the C ABI == oracle; %llu episodes\n", (unsigned long long)n, steps,
-                (unsigned long long)episodes);
+    std::printf("OK %llu boards x %u steps through the C ABI == oracle; %llu episodes; + fused observation and "
+                "host-resident steps\n", (unsigned long long)n, steps, (unsigned long long)episodes);
     return 0;
 }

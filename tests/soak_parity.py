@@ -24,6 +24,8 @@ ora = OracleBatch(n, 2025, threads=0)
 ora.illegal_move_reward = -1.0
 eng.reset()
 ora.reset()
+obs_u8 = torch.zeros((n, 16, 4, 4), dtype=torch.uint8, device=eng.device)     # the step writes its observation itself,
+obs_f16 = torch.zeros((n, 16, 4, 4), dtype=torch.float16, device=eng.device)  # alternating between two dtypes
 gen = torch.Generator(device=eng.device)
 gen.manual_seed(1)
 t0 = time.time()
@@ -35,7 +37,8 @@ for s in range(steps):
     rnd = torch.rand(n, device=eng.device, generator=gen) < noise
     rand_a = torch.randint(0, 4, (n,), device=eng.device, generator=gen, dtype=torch.uint8)
     acts = torch.where(rnd, rand_a, choice)
-    eng.step(acts)
+    obs = obs_u8 if s % 2 == 0 else obs_f16
+    eng.step(acts, obs=obs)
     ora.step(acts.cpu().numpy())
     assert np.array_equal(eng.reward.cpu().numpy(), ora.reward), s
     assert np.array_equal(eng.terminated.cpu().numpy(), ora.terminated), s
@@ -44,6 +47,7 @@ for s in range(steps):
         assert np.array_equal(eng.get_scores(), ora.score), s
         assert np.array_equal(eng.get_last_scores(), ora.last_score), s
         assert np.array_equal(eng.highest.cpu().numpy(), ora.highest), s
+        assert np.array_equal(obs.cpu().numpy(), ora.onehot().astype(obs.cpu().numpy().dtype)), s   # fused observation
 st = eng.episode_stats()
 assert st["episodes"] == int(ora.ep_count.sum())
 print(f"soak ok: 2^{lg} boards x {steps} steps bit-exact vs oracle in {time.time() - t0:.0f} s; episodes {st['episodes']}, "
