@@ -259,6 +259,39 @@ def test_rollout_paths_agree(torch_cuda):
     assert torch.equal(rew, torch.stack(rewards)) and torch.equal(term, torch.stack(terms))
 
 
+@pytest.mark.parametrize("dtype_name", ["uint8", "int32", "int64"])
+def test_fused_rollout_pipeline_every_tail_length(torch_cuda, dtype_name):
+    """rollout_fused_kernel runs its action loads four steps ahead over two register sets, eight steps per loop trip:
+    every rollout length from 1 to 19 (no full trip, exactly one, trips plus every tail length) and a ragged batch
+    must give the per-step launches' outputs bit for bit, for every action dtype."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    n, seed = 777, 5
+    dt = getattr(torch, dtype_name)
+    for k in list(range(1, 20)) + [24, 33]:
+        a, b = Batched2048(n, seed=seed, illegal_move_reward=-3.0), Batched2048(n, seed=seed, illegal_move_reward=-3.0)
+        a.reset()
+        b.reset()
+        a.rollout_random(7)
+        b.rollout_random(7)
+        acts = a.random_actions(k).to(dt)
+        outs = []
+        for eng, fused in ((a, False), (b, True)):
+            rew = torch.full((k, n), 7.0, dtype=torch.float32, device=eng.device)
+            term = torch.full((k, n), 9, dtype=torch.uint8, device=eng.device)
+            ill = torch.full((k, n), 9, dtype=torch.uint8, device=eng.device)
+            hi = torch.full((k, n), 99, dtype=torch.uint8, device=eng.device)
+            eng.rollout(acts, reward=rew, terminated=term, illegal=ill, highest=hi, fused=fused)
+            outs.append((rew, term, ill, hi))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (k, dtype_name)
+        assert np.array_equal(a.get_boards(), b.get_boards()) and np.array_equal(a.get_scores(), b.get_scores()), k
+        assert np.array_equal(a.get_last_scores(), b.get_last_scores()) and a.clock == b.clock, k
+        assert a.episode_stats() == b.episode_stats(), k
+        a.close()
+        b.close()
+
+
 def test_full_size_invariants(torch_cuda):
     """BASELINE's 2^20-board configuration: size-independent properties instead of a full oracle run.
     (1) sharding invariance: board i of a 2^20 batch == board i of the 2-shard run;
