@@ -278,6 +278,9 @@ def test_drop_ins_take_gymnasium_and_sb3_base_classes_when_present(monkeypatch):
     class VecEnv:
         def __init__(self, num_envs, observation_space, action_space):
             self.init_args = (num_envs, observation_space, action_space)
+            # what SB3's VecEnv.__init__ does: it reads every env's render_mode through get_attr BEFORE the subclass
+            # body has run any further -- the adapter must have set what get_attr touches by then
+            self.render_modes_seen = self.get_attr("render_mode")
 
     vec.VecEnv = VecEnv
     for name, mod in (("gymnasium", gym), ("gymnasium.spaces", spaces), ("stable_baselines3", sb3),
@@ -295,6 +298,7 @@ def test_drop_ins_take_gymnasium_and_sb3_base_classes_when_present(monkeypatch):
         assert e.action_space == ("Discrete", 4) and e.observation_space == ("Box", (16, 4, 4))
         v = vec_mod.Vec2048(8, engine=OracleEngine(8, 3))
         assert v.init_args[0] == 8 and v.num_envs == 8 and v.reset().shape == (8, 16, 4, 4)
+        assert v.render_modes_seen == [None] * 8
     finally:
         for name in ("gymnasium", "gymnasium.spaces", "stable_baselines3", "stable_baselines3.common",
                      "stable_baselines3.common.vec_env"):
