@@ -492,6 +492,63 @@ G2048_DEV Board fresh_record_lut(uint32_t w1, uint32_t w2, const Tables &tb)
 // word j (0..3) of entry p of the one-tile table: 1 in byte p & 3 of register p >> 2
 G2048_DEV uint32_t onehot_cell_word(uint32_t p, uint32_t j) { return (p >> 2) == j ? 1u << (8u * (p & 3u)) : 0u; }
 
+// --------------------------------------------------------------------- stack() four cells at a time
+// game2048_env.py:17-32: channel c of the observation = (cell == 2^c), i.e. (exponent == c).  All of one 32-bit word's
+// four cells against one channel: t = cells ^ splat(c) has every byte < 0x40, so 0x80808080 - t has bit 7 set exactly
+// in the bytes where t == 0 and no borrow crosses a byte.  An exponent >= 16 matches no channel (all-zero column).
+G2048_DEV uint32_t eq_flags(uint32_t cells, uint32_t splat) { return (kHigh1 - (cells ^ splat)) & kHigh1; }             // 0x80 per match
+G2048_DEV uint32_t eq_ones(uint32_t cells, uint32_t splat) { return ((kHigh1 - (cells ^ splat)) >> 7) & 0x01010101u; } // uint8 1 per match
+
+// the same four cells as fp16 (two words: cells 0,1 and 2,3; 1.0 = 0x3c00) and fp32 (four words; 1.0 = 0x3f800000):
+// the matching bytes become 0x3c / 0x3f, and v_perm puts each one in the top byte of its half / word
+struct OneHot4F16 { uint32_t lo, hi; };
+struct OneHot4F32 { uint32_t w[4]; };
+
+G2048_DEV OneHot4F16 onehot4_f16(uint32_t cells, uint32_t splat)
+{
+    const uint32_t f = eq_flags(cells, splat);
+    const uint32_t g = (f - (f >> 7)) & 0x3c3c3c3cu;
+    return OneHot4F16{g2048_perm(g, g, 0x010c000cu), g2048_perm(g, g, 0x030c020cu)};
+}
+
+G2048_DEV OneHot4F32 onehot4_f32(uint32_t cells, uint32_t splat)
+{
+    const uint32_t f = eq_flags(cells, splat);            // 0x80 in the matching bytes: byte 2 of 1.0f
+    const uint32_t g = (f - (f >> 7)) & 0x3f3f3f3fu;      // 0x3f there: byte 3 of 1.0f
+    return OneHot4F32{{g2048_perm(g, f, 0x04000c0cu), g2048_perm(g, f, 0x05010c0cu), g2048_perm(g, f, 0x06020c0cu),
+                       g2048_perm(g, f, 0x07030c0cu)}};
+}
+
+// One 16-byte CHUNK of a wavefront's observation piece.  The 64 boards of a wavefront are consecutive, so their
+// observations are one contiguous piece of the output; the wave parks its 64 records (cells masked) in `recs` and
+// writes the piece with 16-byte stores, chunk s * 64 + lane in store s (g2048_kernels.hip emit_onehot).  Per dtype:
+//   OBS 0  u8 : a chunk = one channel (16 cells) of one board       16 chunks / board, boards 4s .. 4s+3 in store s
+//   OBS 1  f16: a chunk = half a channel (8 cells = rows 2h, 2h+1)  32 chunks / board, boards 2s, 2s+1
+//   OBS 2  f32: a chunk = one row of one channel (4 cells)          64 chunks / board, board s
+// `board` = index (0..63) of the board the chunk belongs to.
+struct alignas(16) Cells16 { uint32_t r[4]; };
+struct alignas(16) Chunk16 { uint32_t w[4]; };
+
+template <int OBS>
+G2048_DEV Chunk16 onehot_chunk(const Cells16 *recs, uint32_t s, uint32_t lane, uint32_t &board)
+{
+    if constexpr (OBS == 0) {
+        board = s * 4u + (lane >> 4);
+        const uint32_t splat = (lane & 15u) * 0x01010101u;
+        const Cells16 v = recs[board];
+        return Chunk16{{eq_ones(v.r[0], splat), eq_ones(v.r[1], splat), eq_ones(v.r[2], splat), eq_ones(v.r[3], splat)}};
+    } else if constexpr (OBS == 1) {
+        board = s * 2u + (lane >> 5);
+        const uint32_t splat = ((lane >> 1) & 15u) * 0x01010101u, half = lane & 1u;
+        const OneHot4F16 a = onehot4_f16(recs[board].r[half * 2u], splat), b = onehot4_f16(recs[board].r[half * 2u + 1u], splat);
+        return Chunk16{{a.lo, a.hi, b.lo, b.hi}};
+    } else {
+        board = s;
+        const OneHot4F32 h = onehot4_f32(recs[board].r[lane & 3u], (lane >> 2) * 0x01010101u);
+        return Chunk16{{h.w[0], h.w[1], h.w[2], h.w[3]}};
+    }
+}
+
 // ---------------------------------------------------------------------- one env step on a record
 struct StepOut {
     uint32_t gain;   // merge score of the move (:85); 0 when illegal

@@ -190,11 +190,7 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 //   u8 : one channel (16 cells) of one board      -> needs the whole record     (ds_read_b128, 4 boards per store)
 //   f16: half a channel (8 cells)                 -> two words of the record    (ds_read_b64,  2 boards per store)
 //   f32: one row of one channel (4 cells)         -> one word of the record     (ds_read_b32,  1 board per store)
-// Byte compare of four cells at once: t = cells ^ splat(channel) has every byte < 0x40, so 0x80808080 - t has
-// bit 7 set exactly in the bytes where t == 0 and no borrow crosses a byte.
-__device__ __forceinline__ uint32_t eq_flags(uint32_t cells, uint32_t splat) { return (kHigh1 - (cells ^ splat)) & kHigh1; }
-__device__ __forceinline__ uint32_t eq_ones(uint32_t cells, uint32_t splat) { return ((kHigh1 - (cells ^ splat)) >> 7) & 0x01010101u; }
-
+// The byte compares (eq_ones / onehot4_f16 / onehot4_f32) live in g2048_device.h, where the host unit test reaches them.
 // Occupancy of the kernels that write observations is CAPPED at 3 workgroups (12 wavefronts) per CU by launching
 // them with this much unused dynamic LDS (6 KiB static + 42 KiB = 48 KiB per workgroup of the CU's 160 KiB).  The
 // kernel is bound by DRAM writes, and every resident wavefront owns its own 16-64 KiB output region: with all 32
@@ -203,6 +199,19 @@ __device__ __forceinline__ uint32_t eq_ones(uint32_t cells, uint32_t splat) { re
 // (tools/ubench/r3_probe.hip part B, profiles/r03_d_probe_*.txt: 2 / 3 / 4 workgroups per CU all beat the uncapped
 // launch; the arithmetic needs a sixth of the issue slots, so nothing is lost on the compute side).
 constexpr uint32_t kObsOccupancyPad = 42u * 1024u;
+
+template <int OBS, bool FULL>
+__device__ __forceinline__ void emit_onehot_as(const Cells16 *recs, uint4 *out, uint32_t lane, uint32_t n_here)
+{
+    constexpr uint32_t kStores = 16u << OBS; // 16 / 32 / 64 KiB per wavefront
+#pragma unroll 16
+    for (uint32_t s = 0; s < kStores; ++s) {
+        uint32_t b;
+        const Chunk16 c = onehot_chunk<OBS>(recs, s, lane, b);
+        if (FULL || b < n_here)
+            store_chunk_nt(out, s * 64u + lane, c.w[0], c.w[1], c.w[2], c.w[3]);
+    }
+}
 
 template <bool FULL>
 __device__ __forceinline__ void emit_onehot(uint4 *wave_recs, const Board &rec, void *obs, uint32_t obs_dtype,
@@ -215,45 +224,15 @@ __device__ __forceinline__ void emit_onehot(uint4 *wave_recs, const Board &rec, 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // boards of this wave that exist (ragged last block only)
     const uint32_t n_here = FULL ? 64u : (wave_first < n ? (n - wave_first < 64u ? n - wave_first : 64u) : 0u);
-    if (obs_dtype == 0u) {
-        uint4 *out = static_cast<uint4 *>(obs) + static_cast<uint64_t>(wave_first) * 16u;
-        const uint32_t splat = (lane & 15u) * 0x01010101u;
-#pragma unroll
-        for (uint32_t s = 0; s < 16u; ++s) {
-            const uint32_t b = s * 4u + (lane >> 4);
-            const uint4 v = wave_recs[b];
-            if (FULL || b < n_here)
-                store_chunk_nt(out, s * 64u + lane, eq_ones(v.x, splat), eq_ones(v.y, splat), eq_ones(v.z, splat),
-                               eq_ones(v.w, splat));
-        }
-    } else if (obs_dtype == 1u) {
-        uint4 *out = static_cast<uint4 *>(obs) + static_cast<uint64_t>(wave_first) * 32u;
-        const uint32_t splat = ((lane >> 1) & 15u) * 0x01010101u;
-        const uint2 *halves = reinterpret_cast<const uint2 *>(wave_recs) + (lane & 1u); // rows 0,1 or rows 2,3
-#pragma unroll
-        for (uint32_t s = 0; s < 32u; ++s) {
-            const uint32_t b = s * 2u + (lane >> 5);
-            const uint2 v = halves[b * 2u];
-            // 0x3c in the bytes that match (fp16 1.0 = 0x3c00), then each byte becomes the high byte of a half
-            const uint32_t f0 = eq_flags(v.x, splat), f1 = eq_flags(v.y, splat);
-            const uint32_t g0 = (f0 - (f0 >> 7)) & 0x3c3c3c3cu, g1 = (f1 - (f1 >> 7)) & 0x3c3c3c3cu;
-            if (FULL || b < n_here)
-                store_chunk_nt(out, s * 64u + lane, g2048_perm(g0, g0, 0x010c000cu), g2048_perm(g0, g0, 0x030c020cu),
-                               g2048_perm(g1, g1, 0x010c000cu), g2048_perm(g1, g1, 0x030c020cu));
-        }
-    } else {
-        uint4 *out = static_cast<uint4 *>(obs) + static_cast<uint64_t>(wave_first) * 64u;
-        const uint32_t splat = (lane >> 2) * 0x01010101u;
-        const uint32_t *rows = reinterpret_cast<const uint32_t *>(wave_recs) + (lane & 3u);
-#pragma unroll 16
-        for (uint32_t s = 0; s < 64u; ++s) {
-            const uint32_t f = eq_flags(rows[s * 4u], splat);             // 0x80 in the matching bytes
-            const uint32_t g = (f - (f >> 7)) & 0x3f3f3f3fu;              // 0x3f there: fp32 1.0 = 0x3f800000
-            if (FULL || s < n_here)
-                store_chunk_nt(out, s * 64u + lane, g2048_perm(g, f, 0x04000c0cu), g2048_perm(g, f, 0x05010c0cu),
-                               g2048_perm(g, f, 0x06020c0cu), g2048_perm(g, f, 0x07030c0cu));
-        }
-    }
+    const Cells16 *recs = reinterpret_cast<const Cells16 *>(wave_recs);
+    // the wave's piece starts at board wave_first: 16 << dtype chunks of 16 bytes per board
+    uint4 *out = static_cast<uint4 *>(obs) + (static_cast<uint64_t>(wave_first) << (4u + obs_dtype));
+    if (obs_dtype == 0u)
+        emit_onehot_as<0, FULL>(recs, out, lane, n_here);
+    else if (obs_dtype == 1u)
+        emit_onehot_as<1, FULL>(recs, out, lane, n_here);
+    else
+        emit_onehot_as<2, FULL>(recs, out, lane, n_here);
 }
 
 // ------------------------------------------------------------------- host-visible completion

@@ -69,11 +69,6 @@ def make_spaces():
         return _Space(n=4, shape=(), dtype=np.int64), _Space(low=0, high=1, shape=(16, 4, 4), dtype=np.dtype(int))
 
 
-def _exp_to_values(e):
-    e = np.asarray(e).astype(np.int64)
-    return np.where(e > 0, np.int64(1) << e, np.int64(0))
-
-
 def _values_to_exp(v):
     v = np.asarray(v).astype(np.int64)
     out = np.zeros(v.shape, np.uint8)

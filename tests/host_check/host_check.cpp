@@ -259,6 +259,27 @@ static void store_rng(g2048o_pcg64 *r, const Pcg64 &p)
     r->state_lo = p.state_lo; r->state_hi = p.state_hi; r->inc_lo = p.inc_lo; r->inc_hi = p.inc_hi; r->buf = p.buf;
 }
 
+// The observation piece of ONE wavefront (64 boards, records with their spare bits set as the engine keeps them),
+// built exactly as emit_onehot does on the device: records parked with the cells masked, chunk s * 64 + lane of store
+// s from onehot_chunk<OBS>.  out: 64 boards x 16 channels x 16 cells of 1 / 2 / 4 bytes.
+void hostcheck_onehot_wave(const uint8_t *records, int obs_dtype, uint8_t *out)
+{
+    Cells16 recs[64];
+    for (int l = 0; l < 64; ++l) {
+        const Board cells = record_cells(load_board(records + 16 * l));
+        for (int k = 0; k < 4; ++k)
+            recs[l].r[k] = cells.r[k];
+    }
+    const uint32_t stores = 16u << obs_dtype;
+    for (uint32_t s = 0; s < stores; ++s)
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            uint32_t board;
+            const Chunk16 c = obs_dtype == 0 ? onehot_chunk<0>(recs, s, lane, board)
+                              : obs_dtype == 1 ? onehot_chunk<1>(recs, s, lane, board) : onehot_chunk<2>(recs, s, lane, board);
+            std::memcpy(out + (static_cast<size_t>(s) * 64 + lane) * 16, c.w, 16);
+        }
+}
+
 uint64_t hostcheck_pcg64_next64(g2048o_pcg64 *r) { Pcg64 p = load_rng(r); const uint64_t v = pcg64_next64(p); store_rng(r, p); return v; }
 uint32_t hostcheck_pcg64_next32(g2048o_pcg64 *r) { Pcg64 p = load_rng(r); const uint32_t v = pcg64_next32(p); store_rng(r, p); return v; }
 uint32_t hostcheck_pcg64_interval(g2048o_pcg64 *r, uint32_t mx) { Pcg64 p = load_rng(r); const uint32_t v = pcg64_interval(p, mx); store_rng(r, p); return v; }

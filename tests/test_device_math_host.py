@@ -250,3 +250,30 @@ def test_random_rollouts_records_vs_oracle(host_check, seed, offset, irw, max_ex
                   "ep_count", "ep_start", "terminal_boards"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), (f, s)
     assert a.ep_count.sum() > 100
+
+
+@pytest.mark.parametrize("obs_dtype,np_dtype", [(0, np.uint8), (1, np.float16), (2, np.float32)])
+def test_onehot_chunks_of_a_wavefront(host_check, oracle_lib, obs_dtype, np_dtype):
+    """The observation the step kernel writes (g2048_step_io.obs): onehot_chunk<OBS> of g2048_device.h -- the SWAR
+    byte compare, the fp16 / fp32 expansion through v_perm, and the chunk -> (board, channel, cells) mapping of a
+    wavefront's 64 boards -- against the reference's own stack() outputs (tests/golden/stack_table.npz, incl. 2^16 /
+    2^17 tiles) and against the oracle for random boards, with the records' spare (deficit) bits set."""
+    import ctypes as C
+    t = load_golden("stack_table")
+    rng = np.random.default_rng(obs_dtype)
+    fn = host_check.hostcheck_onehot_wave
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    elem = np.dtype(np_dtype).itemsize
+    batches = [(t["boards"][:64], t["onehot"][:64])]
+    for _ in range(20):                                          # random exponents 0..17, many empties
+        b = (rng.integers(0, 18, (64, 16)) * (rng.random((64, 16)) < 0.7)).astype(np.uint8)
+        want = np.zeros((64, 16, 4, 4), np.uint8)
+        oracle_lib.g2048o_onehot_batch(b.ctypes.data, 64, want.ctypes.data)
+        batches.append((b, want))
+    for boards, want in batches:
+        rec = np.ascontiguousarray(boards, dtype=np.uint8).copy()
+        rec[:, 8:] |= (rng.integers(0, 8, (64, 8)) << 5).astype(np.uint8)   # the packed score deficit must not leak
+        out = np.zeros(64 * 256 * elem, np.uint8)
+        fn(rec.ctypes.data, obs_dtype, out.ctypes.data)
+        got = out.view(np_dtype).reshape(64, 16, 4, 4)
+        assert np.array_equal(got, np.asarray(want).reshape(64, 16, 4, 4).astype(np_dtype))
