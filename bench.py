@@ -469,3 +469,7 @@ def main():
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
