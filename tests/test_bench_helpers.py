@@ -52,3 +52,18 @@ def test_committed_bench_lines_carry_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e8          # the north-star target
+
+
+def test_bench_script_runs_its_main():
+    """bench.py must execute main() when run as a script (the driver calls `python bench.py ...`): --help prints the
+    contract's flags, and without a GPU the run ends with the "needs a ROCm GPU" message instead of silence."""
+    import subprocess
+    import sys
+    bench_py = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench_py, "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([sys.executable, bench_py, "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode != 0 and "needs a ROCm GPU" in (out.stderr + out.stdout)
