@@ -204,7 +204,8 @@ template <int OBS, bool FULL>
 __device__ __forceinline__ void emit_onehot_as(const Cells16 *recs, uint4 *out, uint32_t lane, uint32_t n_here)
 {
     constexpr uint32_t kStores = 16u << OBS; // 16 / 32 / 64 KiB per wavefront
-#pragma unroll 16
+    constexpr uint32_t kUnroll = OBS == 2 ? 16u : kStores;
+#pragma unroll kUnroll
     for (uint32_t s = 0; s < kStores; ++s) {
         uint32_t b;
         const Chunk16 c = onehot_chunk<OBS>(recs, s, lane, b);
