@@ -191,14 +191,30 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 //   f16: half a channel (8 cells)                 -> two words of the record    (ds_read_b64,  2 boards per store)
 //   f32: one row of one channel (4 cells)         -> one word of the record     (ds_read_b32,  1 board per store)
 // The byte compares (eq_ones / onehot4_f16 / onehot4_f32) live in g2048_device.h, where the host unit test reaches them.
-// Occupancy of the kernels that write observations is CAPPED at 3 workgroups (12 wavefronts) per CU by launching
-// them with this much unused dynamic LDS (6 KiB static + 42 KiB = 48 KiB per workgroup of the CU's 160 KiB).  The
+// Occupancy of the kernels that write observations is CAPPED at 2 workgroups (8 wavefronts) per CU by launching
+// them with this much unused dynamic LDS (6 KiB static + 58 KiB = 64 KiB per workgroup of the CU's 160 KiB).  The
 // kernel is bound by DRAM writes, and every resident wavefront owns its own 16-64 KiB output region: with all 32
 // wave slots of a CU filled the chip writes into 8 192 regions at once (128 MiB of open write window at u8) and the
-// memory system runs at 5.1-5.7 TB/s; with 12 it reaches 5.7-6.2 TB/s -- -10 % time at 2^20 boards, -7 % at 2^24
-// (tools/ubench/r3_probe.hip part B, profiles/r03_d_probe_*.txt: 2 / 3 / 4 workgroups per CU all beat the uncapped
-// launch; the arithmetic needs a sixth of the issue slots, so nothing is lost on the compute side).
-constexpr uint32_t kObsOccupancyPad = 42u * 1024u;
+// memory system runs at 5.1 TB/s; narrowing the window to 2 048 regions brings 5.9-6.1 TB/s (u8, 2^20 and 2^22
+// boards: 60.5 -> 52.6 us and 239 -> 201 us; f16 103 -> 99 us; f32 is insensitive; tools/ubench/r3_probe.hip parts B
+// and C, profiles/r03_d_probe_*.txt, r03_l_probe_c_*.txt; at 2^24 boards 3-4 workgroups per CU are ~3 % better
+// than 2, all of them 4-9 % better than uncapped).  The arithmetic needs a sixth of the issue slots, so nothing is
+// lost on the compute side.
+constexpr uint32_t kObsOccupancyPad = 58u * 1024u;
+
+// dynamic LDS above 48 KiB is opt-in per kernel and per device
+template <class Kernel>
+static void allow_obs_pad(Kernel kernel, bool (&done)[64])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        dev = 0;
+    if (done[dev])
+        return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kObsOccupancyPad));
+    done[dev] = true;
+}
 
 template <int OBS, bool FULL>
 __device__ __forceinline__ void emit_onehot_as(const Cells16 *recs, uint4 *out, uint32_t lane, uint32_t n_here)
@@ -1120,8 +1136,15 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     const StepTail tail{a.terminated, a.st.last_record, a.illegal, a.highest, a.terminal_boards, a.illegal_reward, a.max_exp,
                         a.auto_reset, a.obs, a.obs_dtype, a.boards_out, a.done_seq, a.done_value};
 #define G2048_STEP_LAUNCH(ACT, FULL, STD, OBS)                                                                          \
-    hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, (OBS) ? kObsOccupancyPad : 0u, s, a.st.boards, a.actions, \
-                       a.st.ep_counters, a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail)
+    do {                                                                                                                \
+        if (OBS) {                                                                                                      \
+            static bool pad_allowed[64] = {};                                                                           \
+            allow_obs_pad(&step_kernel<ACT, FULL, STD, OBS>, pad_allowed);                                              \
+        }                                                                                                               \
+        hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, (OBS) ? kObsOccupancyPad : 0u, s, a.st.boards,     \
+                           a.actions, a.st.ep_counters, a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n,      \
+                           a.reward, tail);                                                                             \
+    } while (0)
 #define G2048_STEP(ACT, FULL)                                                                                           \
     do {                                                                                                                \
         if (standard && a.obs)                                                                                          \

@@ -11,7 +11,8 @@
 //          the LDS transpose, plain instead of nt stores, observation before the record store, other block sizes,
 //          and a grouped form in which every wavefront walks G groups of 64 boards with the next group's record and
 //          action loads issued before the current group's observation stores.
-// Usage: r3_probe [log2_boards] [rounds] [part: a|b|ab]
+//  part C  the product's observation-writing kernel, u8 / f16 / f32 observations, at different occupancy caps.
+// Usage: r3_probe [log2_boards] [rounds] [part: any of a b c]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -269,6 +270,41 @@ int main(int argc, char **argv)
         const float med = us[v][us[v].size() / 2];
         printf("%-92s %8.2f %8.2f   -> %5.0f GB/s on %3.0f B/board\n", vs[v].name.c_str(), med, us[v][0],
                vs[v].bytes_per_board * n / (med * 1e-6) / 1e9, vs[v].bytes_per_board);
+    }
+
+    // ---- part C: the product's observation-writing kernel for every observation dtype at different occupancy caps
+    //      (dynamic LDS per workgroup on top of the 6 KiB it uses: 0 -> 8 workgroups per CU by VGPRs, 26 KiB -> 5,
+    //      34 -> 4, 42 -> 3 [what the product launches with], 58 -> 2)
+    if (strchr(part, 'c')) {
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<1, true, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        uint8_t *big;
+        const int lc = launches < 8 ? launches : 8;
+        CHECK(hipMalloc(&big, (size_t)n * lc * 1024));
+        CHECK(hipMemset(big, 0, (size_t)n * lc * 1024));
+        for (uint32_t dt = 0; dt < 3; ++dt)
+            for (uint32_t pad : {0u, 26u, 34u, 42u, 58u}) {
+                std::vector<float> t;
+                for (int r = 0; r < rounds + 1; ++r) {
+                    CHECK(hipEventRecord(e0, s0));
+                    for (int j = 0; j < lc; ++j) {
+                        io(j);
+                        const StepTail tail{a.terminated, a.st.last_record, nullptr, nullptr, nullptr, 0.0f, 0u, 1u,
+                                            big + ((size_t)j * n << (8 + dt)), dt, nullptr, nullptr, 0ull};
+                        hipLaunchKernelGGL((step_kernel<1, true, true, true>), dim3(n / 256), dim3(256), pad * 1024u, s0, a.st.boards,
+                                           a.actions, a.st.ep_counters, a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n, a.reward, tail);
+                    }
+                    CHECK(hipEventRecord(e1, s0));
+                    CHECK(hipEventSynchronize(e1));
+                    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (r > 0) t.push_back(ms * 1e3f / lc);
+                }
+                std::sort(t.begin(), t.end());
+                const double bytes = 38.0 + (256 << dt);
+                printf("C  product HAS_OBS kernel, %s observation, %2u KiB pad: %8.2f us per launch (median) -> %5.0f GB/s on %4.0f B/board\n",
+                       dt == 0 ? "u8 " : (dt == 1 ? "f16" : "f32"), pad, t[t.size() / 2], bytes * n / (t[t.size() / 2] * 1e-6) / 1e9, bytes);
+            }
+        CHECK(hipFree(big));
     }
 
     // ---- part A, overlap: the two halves of the batch as independent chains on two streams, the kernels' occupancy
