@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) compute_only_kernel(const Flat p)
 }
 
 // ------------------------------------------------------------------------------------------------ part B
-enum { O_MEMONLY = 1, O_PERLANE = 2, O_PLAIN = 4, O_OBS_FIRST = 8, O_NO_OBS = 16 };
+enum { O_MEMONLY = 1, O_PERLANE = 2, O_PLAIN = 4, O_OBS_FIRST = 8, O_NO_OBS = 16, O_PHILOX_FIRST = 32 };
 
 __device__ __forceinline__ void store_chunk(uint4 *out, uint64_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d, bool plain)
 {
@@ -125,6 +125,12 @@ __global__ void __launch_bounds__(BS) obs_kernel(const Flat p)
     sp.st.ep_counters = p.ep_counters;
     LdsTables tb{};
     bool staged = false;
+    Words w_all[G];
+    if (X & O_PHILOX_FIRST) { // every group's Philox block before any loaded value is needed: work for the ramp
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            w_all[g] = philox4x32_10(p.t_lo, 0u, i + g * BS, 0u, p.seed_lo, 0u);
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g, i += BS) {
         Board rec = rec_next;
@@ -134,7 +140,7 @@ __global__ void __launch_bounds__(BS) obs_kernel(const Flat p)
             act_next = __builtin_nontemporal_load(p.actions + i + BS);
         }
         const EpisodeCounters counters = load_episode_counters(sp, i);
-        const Words w = philox4x32_10(p.t_lo, 0u, i, 0u, p.seed_lo, 0u);
+        const Words w = (X & O_PHILOX_FIRST) ? w_all[g] : philox4x32_10(p.t_lo, 0u, i, 0u, p.seed_lo, 0u);
         if (!staged) {
             tb = stage_tables(s_tables, use_after(piece, w.w[0]));
             staged = true;
@@ -224,6 +230,11 @@ int main(int argc, char **argv)
         vs.push_back({"A  grouped step: 2 groups per wavefront, next group's loads issued before this group's arithmetic", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 256, 2>(flat(j), s); }});
         vs.push_back({"A  grouped step: 4 groups per wavefront", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 256, 4>(flat(j), s); }});
         vs.push_back({"A  grouped step: 2 groups per wavefront, 64-lane blocks", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS, 64, 2>(flat(j), s); }});
+        vs.push_back({"A  grouped step, 2 groups, BOTH Philox blocks before the first record is needed", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_PHILOX_FIRST, 256, 2>(flat(j), s); }});
+        vs.push_back({"A  grouped step, 4 groups, all Philox blocks first", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_PHILOX_FIRST, 256, 4>(flat(j), s); }});
+        vs.push_back({"A  grouped step, 2 groups, Philox first, 128-lane blocks", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_PHILOX_FIRST, 128, 2>(flat(j), s); }});
+        vs.push_back({"A  grouped step, 2 groups, Philox first, 512-lane blocks", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_PHILOX_FIRST, 512, 2>(flat(j), s); }});
+        vs.push_back({"A  1 group, Philox first (= product order; sanity)", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_PHILOX_FIRST, 256, 1>(flat(j), s); }});
         vs.push_back({"A  grouped memory-only: 2 groups per wavefront", 38, [&](uint32_t j, hipStream_t s) { launch_obs<O_NO_OBS | O_MEMONLY, 256, 2>(flat(j), s); }});
     }
     if (strchr(part, 'b')) {
