@@ -425,7 +425,8 @@ class Batched2048:
     def host_io(self) -> dict:
         """numpy views of the engine's pinned, device-mapped host block (``g2048_host_io``): ``actions`` int64[n]
         (IN), ``reward`` float32[n], ``terminated`` / ``illegal`` / ``highest`` uint8[n], ``boards`` and
-        ``terminal_boards`` uint8[n,4,4], ``scores`` int32[n].  ``step_host`` / ``fetch_host`` fill them in place."""
+        ``terminal_boards`` uint8[n,4,4], ``scores`` int32[n].  ``step_host`` / ``fetch_host`` fill them in place.
+        The views alias engine-owned memory: they are valid until ``close()`` (copy what must outlive the engine)."""
         if getattr(self, "_host_io", None) is None:
             raw = HostIO()
             check(self._lib.g2048_host_io_map(self._h, C.byref(raw)))

@@ -357,6 +357,42 @@ def gen_render_fixture(ref, rng):
                 texts=np.array(texts))
 
 
+def gen_render_rgb_fixture(ref, rng):
+    """render('rgb_array') (game2048_env.py:116-154) drawn by the reference's OWN code.  The reference asks Pillow for
+    'Arial.ttf' (:140), which this image does not have (its render raises OSError here); for the capture -- and only
+    there -- ImageFont.truetype is wrapped so that 'Arial.ttf' resolves to the image's DejaVuSans.ttf at the same
+    size.  Everything else (geometry, colour map, text placement through textbbox) is the reference's.  The font
+    actually used is recorded; the build's renderer falls back to the same file when Arial is absent."""
+    from PIL import ImageFont
+    real = ImageFont.truetype
+
+    def truetype(font=None, size=10, *a, **k):
+        return real("DejaVuSans.ttf" if font == "Arial.ttf" else font, size, *a, **k)
+
+    boards, images = [], []
+    ImageFont.truetype = truetype
+    try:
+        # tiles up to 512 only: with the wider substitute font a four-digit label exceeds the 70-pixel cell and the
+        # reference's own assert (:151) fires; the colours of 1024..4096 are pinned by value in test_host_logic.py
+        exps = [np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 0, 0, 1, 9, 8, 7, 0]),         # nine colours of the map, 1-3 digits
+                np.zeros(16, int), np.array([9] * 16), np.array([1] + [0] * 15)]
+        for _ in range(4):
+            e = rng.integers(0, 10, 16)
+            e[rng.random(16) < 0.3] = 0
+            exps.append(e)
+        for e in exps:
+            env = ref.Game2048Env(render_mode="rgb_array")
+            env.set_board(np.where(e > 0, 1 << e, 0).reshape(4, 4))
+            img = env.render()
+            assert img.shape == (280, 280, 3) and img.dtype == np.uint8
+            boards.append(e.astype(np.uint8))
+            images.append(img.copy())
+    finally:
+        ImageFont.truetype = real
+    return dict(boards=np.array(boards, np.uint8), images=np.array(images, np.uint8),
+                font=np.array(os.path.basename(real("DejaVuSans.ttf", 30).path)))
+
+
 def gen_canonical_table(rng, n=1024):
     """Symmetric-board canonicalisation pinned to the reference's own symmetry code: the eight
     variants of every transition are produced by training_data.hflip()/rotate() (training_data.py:257-280,
@@ -651,6 +687,7 @@ def main():
     ap.add_argument("--only-numpy", action="store_true", help="only (re)generate the numpy-RNG trajectories")
     ap.add_argument("--only-data", action="store_true", help="only (re)generate the training_data fixtures")
     ap.add_argument("--only-round2", action="store_true", help="only (re)generate the fixtures added in round 2")
+    ap.add_argument("--only-round3", action="store_true", help="only (re)generate the fixtures added in round 3")
     args = ap.parse_args()
     ref = import_reference()
     rng = np.random.default_rng(20480)
@@ -679,6 +716,10 @@ def main():
         save("eval_table.npz", gen_eval_table(ref, np.random.default_rng(10)))
         print("\n".join(report))
         return
+    if args.only_round3:
+        save("render_rgb.npz", gen_render_rgb_fixture(ref, np.random.default_rng(11)))
+        print("\n".join(report))
+        return
     save("training_data_fixture.npz", gen_training_data_fixtures(report))
     save("traj_numpy_seed42.npz", gen_numpy_trajectories(ref, 42, 48, 256))
     save("traj_numpy_seed7_irw.npz", gen_numpy_trajectories(ref, 7, 16, 512, illegal_move_reward=-1.0))
@@ -704,6 +745,7 @@ def main():
     save("render_ansi.npz", gen_render_fixture(ref, np.random.default_rng(7)))
     save("canonical_table.npz", gen_canonical_table(np.random.default_rng(8)))
     save("eval_table.npz", gen_eval_table(ref, np.random.default_rng(10)))
+    save("render_rgb.npz", gen_render_rgb_fixture(ref, np.random.default_rng(11)))
     validate(ref, args.validate_steps, report)
     time_reference(ref, report)
     import datetime

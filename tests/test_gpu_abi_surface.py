@@ -166,6 +166,16 @@ def test_canonicalize_vs_reference_table_and_oracle(torch_cuda):
     for i in range(0, 20000, 97):
         wb, _, _, wv = canonicalize(boards[i].reshape(4, 4))
         assert wv == sym[i] and np.array_equal(wb.reshape(16), got[i])
+    # the engine-less entry points find their device from the pointer; a HOST buffer is refused, not dereferenced
+    from gym2048_amd import _lib
+    lib = _lib.load()
+    host = np.zeros((64, 16), np.uint8)
+    host_actions = np.zeros(64, np.uint8)
+    assert lib.g2048_canonicalize(host.ctypes.data, None, None, 64, None, None) == -1
+    assert b"not device memory" in lib.g2048_last_error()
+    out = np.zeros((8 * 64, 16), np.uint8)
+    assert lib.g2048_augment(host.ctypes.data, None, host_actions.ctypes.data, 64, out.ctypes.data, None,
+                             np.zeros(8 * 64, np.uint8).ctypes.data, None) == -1
 
 
 def test_collective_behind_the_c_abi_one_rank(torch_cuda):

@@ -165,6 +165,10 @@ def test_render_modes():
     assert tuple(img[2, 2]) == (255, 0, 0) and tuple(img[278, 100]) == (128, 128, 128)
     assert tile_colour(2) == (255, 0, 0) and tile_colour(512) == (0, 255, 0) and tile_colour(4096) == (0, 160, 96)
     assert tile_colour(4) == (224, 32, 0) and tile_colour(256) == (32, 224, 0) and tile_colour(1024) == (0, 224, 32)
+    # all twelve entries of the reference's colour map (game2048_env.py:120-133), as data
+    ramp = [(255, 0, 0), (224, 32, 0), (192, 64, 0), (160, 96, 0), (128, 128, 0), (96, 160, 0), (64, 192, 0), (32, 224, 0),
+            (0, 255, 0), (0, 224, 32), (0, 192, 64), (0, 160, 96)]
+    assert [tile_colour(1 << k) for k in range(1, 13)] == ramp
     with pytest.raises(KeyError):
         tile_colour(8192)
     assert "4.0" in render_board(np.zeros((4, 4), int), 4.0, "ansi").getvalue()

@@ -251,3 +251,24 @@ def test_validation_report_covers_every_fixture():
     m = re.search(r"validated (\d+) env-steps .* of the imported reference against the C oracle and the Python oracle: "
                   r"all .* identical", report)
     assert m and int(m.group(1)) >= 900_000
+
+
+def test_render_rgb_matches_the_reference_image():
+    """render('rgb_array') (game2048_env.py:116-154): 280 x 280 x 3 images drawn by the reference's own code
+    (tests/golden/render_rgb.npz; the missing Arial.ttf replaced by the image's DejaVuSans.ttf for the capture, see
+    make_golden.gen_render_rgb_fixture) -- geometry, colour map and text placement, pixel for pixel, when this
+    process resolves the same font; the colours alone otherwise."""
+    import os
+    from gym2048_amd.render import _font, render_board
+    r = load_golden("render_rgb")
+    same_font = os.path.basename(getattr(_font(30), "path", "") or "") == str(r["font"])
+    for e, want in zip(r["boards"], r["images"]):
+        vals = np.where(e > 0, np.int64(1) << e.astype(np.int64), 0).reshape(4, 4)
+        got = render_board(vals, 0, "rgb_array")
+        assert got.shape == (280, 280, 3) and got.dtype == np.uint8
+        if same_font:
+            assert np.array_equal(got, want)
+        # font-independent part: the cell colours, sampled at each cell's corner region (no glyph reaches it)
+        for y in range(4):
+            for x in range(4):
+                assert np.array_equal(got[y * 70 + 3, x * 70 + 3], want[y * 70 + 3, x * 70 + 3]), (y, x)
