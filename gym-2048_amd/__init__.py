@@ -7,7 +7,7 @@ top.  See DESIGN.md / INTEGRATION.md.
 from ._lib import G2048Error, LIB_PATH  # noqa: F401
 from .env import Game2048Env, IllegalMove, stack  # noqa: F401
 from .vec_env import Vec2048  # noqa: F401
-from .sharding import Shard, shard_range, weak_shard, allgather_returns  # noqa: F401
+from .sharding import Shard, LocalShards, shard_range, weak_shard, allgather_returns  # noqa: F401
 from .evaluate import evaluate_model, report_evaluation_results  # noqa: F401
 
 __version__ = "0.1.0"

@@ -87,3 +87,69 @@ def merge_stats(rows) -> dict:
                highest_hist=[sum(col) for col in zip(*(p["highest_hist"] for p in parts))])
     tot["mean_last_score"] = tot["last_score_sum"] / tot["last_count"] if tot["last_count"] else 0.0
     return tot
+
+
+class LocalShards:
+    """ONE process driving several GPUs of a node -- SURVEY 8e's single-process form of the same layout: engine r on
+    ``devices[r]`` owns global boards ``[r * n_per_gpu, (r + 1) * n_per_gpu)`` (global-index spawn stream: the games
+    do not depend on the split), every call enqueues on each device's current stream so the devices run concurrently,
+    and the once-per-rollout all-gather of episodic returns goes through the library's persistent communicator set
+    (``g2048_comm_local_create``: ncclCommInitAll once; ``g2048_allgather_returns_local``: export kernels + one grouped
+    ncclAllGather, enqueued).  The one-process-per-GPU form (``weak_shard`` + ``torch.distributed``) is what
+    ``bench.py`` uses; this class is for callers that do not want a launcher."""
+
+    def __init__(self, n_per_gpu: int, devices=None, seed: int = 0, **engine_kwargs):
+        import ctypes as C
+        from . import _lib
+        from .batched import Batched2048
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
+        self.devices = [int(d) for d in devices]
+        self.n_per_gpu = int(n_per_gpu)
+        self.engines = [Batched2048(self.n_per_gpu, device=d, seed=seed, board_offset=r * self.n_per_gpu, **engine_kwargs)
+                        for r, d in enumerate(self.devices)]
+        self._lib = _lib.load()
+        self._comm = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        _lib.check(self._lib.g2048_comm_local_create(arr, len(self.devices), C.byref(self._comm)))
+
+    @property
+    def n_global(self) -> int:
+        return self.n_per_gpu * len(self.engines)
+
+    def reset(self, seed=None):
+        for e in self.engines:
+            e.reset(seed=seed)
+
+    def rollout_random(self, k_steps: int):
+        for e in self.engines:                      # launches only: the devices run concurrently
+            e.rollout_random(k_steps)
+
+    def rollout(self, actions, **buffers):
+        """``actions`` (and every optional ``[k, n]`` buffer): one tensor per device, on that device."""
+        for r, e in enumerate(self.engines):
+            e.rollout(actions[r], **{name: buf[r] for name, buf in buffers.items() if buf is not None})
+
+    def allgather_returns(self):
+        """Every device's copy of all ``n_global`` last episodic returns (int32), in global board order.  Enqueued on
+        the devices' current streams; ``synchronize()`` (or using the tensors on those streams) waits for it."""
+        import ctypes as C
+        from . import _lib
+        g = len(self.engines)
+        outs = [torch.empty(self.n_global, dtype=torch.int32, device=e.device) for e in self.engines]
+        eng = (C.c_void_p * g)(*[e._h for e in self.engines])
+        ptrs = (C.c_void_p * g)(*[o.data_ptr() for o in outs])
+        streams = (C.c_void_p * g)(*[torch.cuda.current_stream(e.device).cuda_stream for e in self.engines])
+        _lib.check(self._lib.g2048_allgather_returns_local(self._comm, eng, ptrs, streams))
+        return outs
+
+    def synchronize(self):
+        for e in self.engines:
+            torch.cuda.synchronize(e.device)
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.g2048_comm_local_destroy(self._comm)
+            self._comm = None
+        for e in self.engines:
+            e.close()

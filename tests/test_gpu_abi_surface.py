@@ -222,6 +222,33 @@ def test_collective_behind_the_c_abi_one_rank(torch_cuda):
     assert lib.g2048_comm_create(2, 5, ident, 0, C.byref(comm)) != 0     # rank out of range
 
 
+def test_local_shards_single_process_form(torch_cuda):
+    """gym2048_amd.LocalShards (one process, several GPUs; here the one GPU there is): the shard plays the same
+    games as a plain engine and the all-gather through the persistent communicator returns its last returns."""
+    torch = torch_cuda
+    from gym2048_amd import LocalShards
+    from gym2048_amd.batched import Batched2048
+    n, seed = 1 << 15, 12
+    sh = LocalShards(n, devices=[0], seed=seed)
+    ref = Batched2048(n, seed=seed)
+    sh.reset()
+    ref.reset()
+    for _ in range(3):
+        sh.rollout_random(40)
+        ref.rollout_random(40)
+        outs = sh.allgather_returns()
+        sh.synchronize()
+        assert len(outs) == 1 and np.array_equal(outs[0].cpu().numpy(), ref.get_last_scores())
+    acts = ref.random_actions(6)
+    rew = torch.zeros((6, n), dtype=torch.float32, device=ref.device)
+    rew2 = torch.zeros_like(rew)
+    sh.rollout([acts], reward=[rew2])
+    ref.rollout(acts, reward=rew)
+    assert torch.equal(rew, rew2) and np.array_equal(sh.engines[0].get_boards(), ref.get_boards())
+    assert sh.n_global == n
+    sh.close()
+
+
 def test_misaligned_buffers_are_refused(torch_cuda):
     torch = torch_cuda
     from gym2048_amd import _lib
