@@ -185,7 +185,7 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
     20-launch train must stay small (DESIGN.md section 6 derives the predicted 8-GPU efficiency from it)."""
     import json
     env = dict(os.environ, G2048_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(31000 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_PORT=str(31000 + 2 * (os.getpid() % 1000) + (gather == "full")), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-extras",
