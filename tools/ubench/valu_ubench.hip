@@ -32,6 +32,12 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a, uint32_t b)
             if (OP == 12) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x[i]) : "v"(sel));
             if (OP == 13) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(x[i]) : "v"(sel));
             if (OP == 14) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[i]) : "v"(sel));
+            if (OP == 15) { uint64_t r = ((uint64_t)x[i] << 32) | sel; asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(r) : "v"(a)); x[i] = (uint32_t)(r >> 32); }
+            if (OP == 16) { uint64_t r = ((uint64_t)x[i] << 32) | sel; asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(r) : "v"(a)); x[i] = (uint32_t)r; }
+            if (OP == 17) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(sel), "v"(a));
+            if (OP == 18) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(sel) : "vcc");
+            if (OP == 19) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x[i]) : "v"(a));
+            if (OP == 20) asm volatile("v_bfe_u32 %0, %0, %1, 4" : "+v"(x[i]) : "v"(a));
         }
     }
     uint32_t s = 0;
@@ -67,5 +73,7 @@ int main()
     run<3>("v_bitop3_b32", d); run<9>("v_and_or_b32", d); run<14>("v_lshl_add_u32", d); run<6>("v_lshrrev_b32", d);
     run<7>("v_bcnt_u32_b32", d); run<11>("v_cndmask_b32", d); run<4>("v_mul_hi_u32", d); run<8>("v_mul_lo_u32", d);
     run<5>("v_mad_u64_u32", d); run<12>("v_pk_add_u16", d); run<10>("v_fma_f32", d);
+    run<15>("v_lshlrev_b64", d); run<16>("v_lshrrev_b64", d); run<17>("v_alignbit_b32", d); run<18>("v_cndmask_e64", d);
+    run<19>("v_lshlrev_b32 (var)", d); run<20>("v_bfe_u32", d);
     return 0;
 }
