@@ -214,6 +214,8 @@ def main():
     def barrier():
         if dist_on:
             dist.barrier()
+            dist.barrier()      # twice: ranks ENTER the second one within microseconds of each other, so they also leave
+                                # it together -- the exit skew of a barrier would otherwise be counted by whoever left first
         torch.cuda.synchronize()
 
     host_gather = backend != "nccl" and dist_on        # gloo smoke test: collectives on host copies
