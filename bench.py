@@ -25,9 +25,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   `traffic` = HBM bytes per launch from the committed PMC profile, printed only while the
                   profile was taken from the kernel sources that are being run (hash of csrc/), else null
   cpu_baseline -- the C oracle (oracle/, "port") timed on this box's host cores on a bounded sample
-  extras       -- a 2^24-board run that really streams HBM (best of 3), the step + one-hot observation
-                  figure, the policy-in-the-loop figure (BASELINE configs[4]), fused rollout kernels,
-                  numpy-RNG mode, Python port
+  extras       -- a 2^24-board run that really streams HBM (best of 4), the step that writes its one-hot observation
+                  (one launch), the policy-in-the-loop figure (BASELINE configs[4]), fused rollout kernels,
+                  numpy-RNG mode, the single-env host path, Python port
 """
 from __future__ import annotations
 
@@ -449,6 +449,24 @@ def main():
             npe.close()
         except Exception as exc:  # pragma: no cover
             extras["numpy_rng_mode_steps_per_s"] = f"error: {exc}"
+        # (b3) the drop-in single env (host arrays, one library call per step through the engine's pinned host block):
+        #      Game2048Env.step + reset on termination, random actions -- what train.py / gather_training_data.py would see
+        try:
+            import numpy as _np
+            from gym2048_amd import Game2048Env
+            env = Game2048Env(device=local_rank)
+            env.reset(seed=SEED)
+            acts = _np.random.default_rng(0).integers(0, 4, 4000)
+            for a in acts[:500]:
+                if env.step(int(a))[2]:
+                    env.reset()
+            t1 = time.perf_counter()
+            for a in acts:
+                if env.step(int(a))[2]:
+                    env.reset()
+            extras["single_env_host_steps_per_s"] = len(acts) / (time.perf_counter() - t1)
+        except Exception as exc:  # pragma: no cover
+            extras["single_env_host_steps_per_s"] = f"error: {exc}"
         out["extras"] = extras
         # (c) CPU legs (rank 0, N = 1 only per the contract; cheap enough to always show at N = 1)
         if world == 1:
