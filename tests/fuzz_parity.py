@@ -53,17 +53,27 @@ def one_case(case):
     max_tile = rs.choice([None, 8, 32, 2048])
     max_tile = None if max_tile is None else int(max_tile)
     auto_reset = bool(rs.random() < 0.8)
-    eng = Batched2048(n, seed=seed, board_offset=offset, illegal_move_reward=irw, max_tile=max_tile)
+    numpy_mode = bool(rs.random() < 0.2)       # the reference's own PCG64 per board (separate kernels)
+    if numpy_mode:
+        n, seed, offset = min(n, 1500), seed % (1 << 40), offset % (1 << 20)
+    eng = Batched2048(n, seed=seed, board_offset=offset, illegal_move_reward=irw, max_tile=max_tile,
+                      rng="numpy" if numpy_mode else "philox")
     ora = OracleBatch(n, seed, offset)
     ora.illegal_move_reward = irw
     ora.max_exp = 0 if max_tile is None else max_tile.bit_length() - 1
+    if numpy_mode:
+        ora.seed_numpy(seed)
+        ora.step = ora.step_numpy               # same signature
     eng.reset()
-    ora.reset()
+    ora.reset_numpy() if numpy_mode else ora.reset()
     dev = eng.device
-    tag = f"case {case}: n={n} seed={seed} offset={offset} irw={irw} max_tile={max_tile} auto_reset={auto_reset}"
+    bump("numpy_mode_cases" if numpy_mode else "philox_cases")
+    tag = f"case {case}: n={n} seed={seed} offset={offset} irw={irw} max_tile={max_tile} auto_reset={auto_reset} numpy={numpy_mode}"
     for call in range(int(rs.integers(12, 40))):
         kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state"],
                              p=[0.3, 0.18, 0.15, 0.08, 0.12, 0.06, 0.05, 0.06]))
+        if numpy_mode and kind in ("fused", "random", "mask_reset"):   # spawn-stream-only calls / unmaskable oracle reset
+            kind = "step"
         where = f"{tag} call {call} {kind}"
         bump(kind)
         if kind == "step":
@@ -84,7 +94,8 @@ def one_case(case):
                 assert np.array_equal(got, ora.onehot().astype(got.dtype)), where
         elif kind in ("rollout", "fused"):
             k = int(rs.integers(1, 20))
-            acts = eng.random_actions(k) if rs.random() < 0.5 else torch.as_tensor(rs.integers(0, 4, (k, n)).astype(np.uint8)).to(dev)
+            acts = (eng.random_actions(k) if rs.random() < 0.5 and not numpy_mode
+                    else torch.as_tensor(rs.integers(0, 4, (k, n)).astype(np.uint8)).to(dev))
             if kind == "fused":
                 acts = acts.to(ADT[int(rs.integers(0, 3))])
             rew = torch.zeros((k, n), dtype=torch.float32, device=dev)
@@ -141,7 +152,7 @@ def one_case(case):
             ora.boards[:] = b
         else:  # state save / restore into a fresh engine that then replaces the original
             blob = eng.state_dict()
-            other = Batched2048(n, seed=1, board_offset=0)
+            other = Batched2048(n, seed=1, board_offset=0, rng="numpy" if numpy_mode else "philox")
             other.load_state_dict(blob)
             eng.close()
             eng = other
