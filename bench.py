@@ -317,6 +317,10 @@ def main():
                      "traffic": traffic, "traffic_provenance": traffic_prov,
                      "kernel": "g2048::step_kernel<1, true, true, false>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us,
+                     "issue_bound_note": "the step kernel saturates integer VALU issue before it saturates HBM: a compute-only "
+                                         "copy of it takes 105.9 us of a 114.6-117.7 us launch at 2^24 boards and 7.8 of 10.2 us "
+                                         "at 2^20, a memory-only copy 105.2 / 7.65 us (tools/ubench/r3_probe.hip part A, "
+                                         "profiles/r03_h_probe_2p24_a.txt, r03_d_probe_2p20.txt; DESIGN.md 5.1)",
                      "note": (f"the {working_set_mib:.0f} MiB of board records touched per launch sit in the 256 MiB "
                               "Infinity Cache at this batch size, so this is a cache-resident figure; "
                               "extras.streaming_2p24 is the run that streams HBM") if B <= (1 << 22) else None},
