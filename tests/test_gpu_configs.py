@@ -208,6 +208,15 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
         assert line["global_returns"]["mean_last_episode_score"] == line["mean_last_episode_score"]
 
 
+def test_policy_loop_bench_small(torch_cuda):
+    """bench_policy.run (BASELINE configs[4] as bench.py's extras.policy_loop measures it) on a small batch: one env
+    launch per step that reads the policy's int64 actions and writes the next fp16 observation, no host copies."""
+    import bench_policy
+    r = bench_policy.run(boards=8192, steps=2, warmup=1, chunk=4096)
+    assert r["boards"] == 8192 and r["host_copies"] == 0 and r["launches_per_env_step"] == 1
+    assert r["value"] > 0 and r["ms_per_step"]["env_step_with_observation"] > 0 and r["episodes_finished"] >= 0
+
+
 def test_more_than_4_gib_of_records(torch_cuda):
     """2^28 + 4133 boards = 4 GiB + of records in ONE engine (the layout is sized for 288 GB): byte offsets of
     the records, the terminal records and the [K][N] float rewards exceed 32 bits.  Sharding invariance makes
