@@ -25,8 +25,7 @@ from gym2048_amd import _lib
 from gym2048_amd.batched import Batched2048
 from oracle import OracleBatch
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rs = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+rs = np.random.default_rng(0)
 DT = {0: torch.uint8, 1: torch.float16, 2: torch.float32}
 ADT = [torch.uint8, torch.int32, torch.int64]
 counts = {}
@@ -162,9 +161,19 @@ def one_case(case):
     eng.close()
 
 
-t0 = time.time()
-case = 0
-while time.time() - t0 < budget:
-    one_case(case)
-    case += 1
-print(f"fuzz ok: {case} cases in {time.time() - t0:.0f} s, calls {dict(sorted(counts.items()))}; every output of every call bit-exact vs the oracle")
+def run(budget: float = 120.0, seed: int = 0) -> str:
+    """Fuzz for ``budget`` seconds; returns the summary line (raises AssertionError on the first mismatch)."""
+    global rs
+    rs = np.random.default_rng(seed)
+    counts.clear()
+    t0 = time.time()
+    case = 0
+    while time.time() - t0 < budget:
+        one_case(case)
+        case += 1
+    return (f"fuzz ok: {case} cases in {time.time() - t0:.0f} s, calls {dict(sorted(counts.items()))}; every output of "
+            f"every call bit-exact vs the oracle")
+
+
+if __name__ == "__main__":
+    print(run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0))
