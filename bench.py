@@ -9,7 +9,10 @@ from, and writing reward/terminated to, [K][B] rollout buffers that are resident
 timed region starts.  Workload = BASELINE configs[2]: B = 2^20 boards per GPU, synthetic uniform
 random policy (actions pre-generated on the device by g2048_fill_random_actions), seed 42.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): rank r owns global boards
+N > 1, one rank per GPU: either under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or as plain `python bench.py --gpus N ...`, which
+starts the N ranks itself (self_launch: same environment, rank 0's JSON line relayed as the LAST line of stdout, worst
+exit code returned; fewer than N visible GPUs -> one clear line on stderr, exit code 2).  Rank r owns global boards
 [r*B, (r+1)*B) -- no data-path collective; one RCCL all-gather of the episodic returns at the end of the
 rollout, inside the timed region and enqueued on the launch stream right behind the K step launches (the
 statistics kernel and the collective start when the last step retires; no host work in between).  The
@@ -160,6 +163,92 @@ def traffic_for_current_sources(boards: int):
     return t.get("bytes_per_launch"), prov
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, cmd, env=None, grace: float = 15.0, timeout: float = None) -> int:
+    """Run ``cmd`` as ``n`` ranks of one node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
+    the environment, as torch.distributed.run would set them), relay what they print and return the worst exit code.
+
+    Output contract: every line rank 0 writes to stdout is passed through in order, EXCEPT that its last JSON line
+    (the bench line) is held back and printed as the very LAST line of this process's stdout; the other ranks'
+    stdout goes to stderr.  If a rank dies, the others get ``grace`` seconds to finish (they are usually stuck in a
+    collective waiting for it) and are then terminated -- by their own PIDs."""
+    import subprocess
+    import threading
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen(list(cmd), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=r == 0))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    t0 = time.monotonic()
+    first_failure = None
+    while True:
+        states = [p.poll() for p in procs]               # poll EVERY rank (any() would stop at the first live one)
+        if all(c is not None for c in states):
+            break
+        time.sleep(0.05)
+        now = time.monotonic()
+        if first_failure is None and any(c not in (None, 0) for c in states):
+            first_failure = now
+        overdue = timeout is not None and now - t0 > timeout
+        if overdue or (first_failure is not None and now - first_failure > grace):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(5)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if overdue:
+                print(f"bench.py: the {n}-rank run exceeded {timeout:.0f} s and was stopped", file=sys.stderr)
+    reader.join(10)
+    codes = [p.wait() for p in procs]
+    last_json = None
+    for idx in range(len(lines) - 1, -1, -1):
+        if lines[idx].lstrip().startswith("{"):
+            last_json = lines.pop(idx)
+            break
+    for ln in lines:
+        sys.stdout.write(ln)
+    if last_json is not None:
+        sys.stdout.write(last_json if last_json.endswith("\n") else last_json + "\n")
+    sys.stdout.flush()
+    worst = 0
+    for r, c in enumerate(codes):
+        if c != 0:
+            print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
+            worst = max(worst, c if c > 0 else 128 - c)      # a rank killed by signal s counts as 128 + s
+    if worst == 0 and last_json is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        worst = 1
+    return worst
+
+
+def self_launch(n: int, argv) -> int:
+    """``python bench.py --gpus N`` (N > 1) started WITHOUT torch.distributed.run: start the N ranks ourselves, one per
+    GPU, with exactly the environment the launcher would have given them (the torchrun form keeps working: it sets
+    WORLD_SIZE and this function is never reached).  Fails with one clear line when the box has fewer than N GPUs."""
+    if os.environ.get("G2048_BENCH_SAME_DEVICE") != "1":          # (that switch puts every rank on cuda:0: gloo smoke test)
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs and this box has {have}; nothing was run", file=sys.stderr)
+            return 2
+    limit = float(os.environ.get("G2048_BENCH_LAUNCH_TIMEOUT", "3000"))
+    return launch_ranks(n, [sys.executable, os.path.abspath(__file__)] + list(argv), timeout=limit)
+
+
 def main():
     args = parse_args()
     import torch
@@ -168,10 +257,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: no launcher around us, so this process becomes the launcher
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-        args.gpus = world
+        args.gpus = world                                # under a launcher the launcher's world size is the truth
+    if os.environ.get("G2048_BENCH_SAME_DEVICE") != "1" and torch.cuda.is_available() and torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but this box has {torch.cuda.device_count()} visible GPU(s)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU; the product has no CPU path")
     # G2048_BENCH_BACKEND=gloo + G2048_BENCH_SAME_DEVICE=1: smoke-test the N > 1 code path on a

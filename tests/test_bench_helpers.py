@@ -67,3 +67,68 @@ def test_bench_script_runs_its_main():
         out = subprocess.run([sys.executable, bench_py, "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
                              timeout=300)
         assert out.returncode != 0 and "needs a ROCm GPU" in (out.stderr + out.stdout)
+
+
+# ---------------------------------------------------------------- the self-launcher (`python bench.py --gpus N`, N > 1)
+_RANK_SCRIPT = r"""
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["LOCAL_WORLD_SIZE"] == os.environ["WORLD_SIZE"]
+mode = sys.argv[1]
+print(f"banner from rank {rank}")
+if mode == "ok":
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "args": sys.argv[2:]}))
+        print("trailing noise from rank 0")          # e.g. a library banner flushed at exit
+elif mode == "fail1":
+    if rank == 1:
+        sys.exit(7)
+    time.sleep(60)                                   # "stuck in a collective": the launcher must stop it
+elif mode == "nojson":
+    pass
+"""
+
+
+def _run_launcher(tmp_path, mode, n=2, grace=1.0):
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    driver = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+              f"sys.exit(bench.launch_ranks({n}, [sys.executable, {str(script)!r}, {mode!r}, '--steps', '20'], grace={grace}))")
+    return subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_relays_rank0_json_as_the_last_stdout_line(tmp_path):
+    out = _run_launcher(tmp_path, "ok", n=3)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    d = json.loads(lines[-1])                                    # the bench line is LAST, whatever rank 0 printed after it
+    assert d == {"n_gpus": 3, "args": ["--steps", "20"]}
+    assert "banner from rank 0" in out.stdout and "trailing noise from rank 0" in lines[:-1]
+    assert "banner from rank 1" in out.stderr and "banner from rank 2" in out.stderr      # other ranks: stderr
+    assert "banner from rank 1" not in out.stdout
+
+
+def test_launcher_propagates_the_worst_exit_code_and_stops_stuck_ranks(tmp_path):
+    import time
+    t0 = time.time()
+    out = _run_launcher(tmp_path, "fail1", n=2, grace=1.0)
+    assert out.returncode == 143 and time.time() - t0 < 30       # rank 1: 7; rank 0 terminated (SIGTERM = 128 + 15)
+    assert "rank 1 exited with 7" in out.stderr and "rank 0 exited with -15" in out.stderr
+    out = _run_launcher(tmp_path, "nojson")
+    assert out.returncode == 1 and "printed no JSON line" in out.stderr
+
+
+def test_bench_gpus_n_without_enough_gpus_fails_with_one_clear_line():
+    """`python bench.py --gpus 8` on a box with fewer GPUs: no launcher needed, no hang, one line, rc != 0."""
+    import subprocess
+    import sys
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "G2048_BENCH_SAME_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 7), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2 and out.stdout == ""
+    assert f"--gpus {have + 7} needs {have + 7} visible GPUs and this box has {have}" in out.stderr

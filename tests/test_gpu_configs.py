@@ -208,6 +208,33 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
         assert line["global_returns"]["mean_last_episode_score"] == line["mean_last_episode_score"]
 
 
+@pytest.mark.parametrize("gather", ["summary", "full"])
+def test_bench_gpus_2_launches_itself(torch_cuda, gather):
+    """The command the driver's scaling run uses -- plain `python bench.py --gpus N --steps 20 --warmup 5`, NO
+    torch.distributed.run around it -- rehearsed with N = 2 on the one GPU there is: bench.py starts the two ranks
+    itself (G2048_BENCH_SAME_DEVICE=1 puts both on cuda:0, G2048_BENCH_BACKEND=gloo carries the collectives, because
+    RCCL refuses two ranks on one device), each rank steps its own HIP shard, the once-per-rollout exchange runs, and
+    rank 0's JSON line comes back as the LAST line of the parent's stdout."""
+    import json
+    env = dict(os.environ, G2048_BENCH_BACKEND="gloo", G2048_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "G2048_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--no-extras", "--gather", gather], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = res.stdout.strip().splitlines()
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert line["config"]["global_boards"] == 2 * line["config"]["boards_per_gpu"] == 2 << 20
+    t = line["timing"]
+    assert t["launch_train_us"] > 0 and t["collective_us"] > 0 and line["value"] > 1e10
+    assert line["episodes_finished"] > 0
+    if gather == "summary":
+        g = line["global_returns"]                      # both ranks' summaries arrived: twice rank 0's shard, roughly
+        assert 1.8 * line["episodes_finished"] < g["episodes"] < 2.2 * line["episodes_finished"]
+    print(f"self-launched 2 ranks ({gather}): {line['value']:.3e} env-steps/s, timing {t}")
+
+
 def test_policy_loop_bench_small(torch_cuda):
     """bench_policy.run (BASELINE configs[4] as bench.py's extras.policy_loop measures it) on a small batch: one env
     launch per step that reads the policy's int64 actions and writes the next fp16 observation, no host copies."""
