@@ -92,14 +92,21 @@ def merge_stats(rows) -> dict:
 class LocalShards:
     """ONE process driving several GPUs of a node -- SURVEY 8e's single-process form of the same layout: engine r on
     ``devices[r]`` owns global boards ``[r * n_per_gpu, (r + 1) * n_per_gpu)`` (global-index spawn stream: the games
-    do not depend on the split), every call enqueues on each device's current stream so the devices run concurrently,
-    and the once-per-rollout all-gather of episodic returns goes through the library's persistent communicator set
-    (``g2048_comm_local_create``: ncclCommInitAll once; ``g2048_allgather_returns_local``: export kernels + one grouped
-    ncclAllGather, enqueued).  The one-process-per-GPU form (``weak_shard`` + ``torch.distributed``) is what
-    ``bench.py`` uses; this class is for callers that do not want a launcher."""
+    do not depend on the split) and the once-per-rollout all-gather of episodic returns goes through the library's
+    persistent communicator set (``g2048_comm_local_create``: ncclCommInitAll once; ``g2048_allgather_returns_local``:
+    export kernels + one grouped ncclAllGather, enqueued).
 
-    def __init__(self, n_per_gpu: int, devices=None, seed: int = 0, **engine_kwargs):
-        import ctypes as C
+    ONE LAUNCH THREAD PER DEVICE (SURVEY 8e "scaling risk"): a ``rollout`` of k steps is k host launches of ~3 us
+    each, so a serial loop over 8 engines would start the last device's first kernel ~8 x k x 3 us after the first
+    device's.  Every engine therefore has its own worker thread (a one-thread executor: calls on one engine stay in
+    order); the C ABI calls are made through ctypes, which releases the GIL, so the launch trains of the devices are
+    issued concurrently.  Each worker enqueues on ITS device's stream ``streams[r]`` (by default the stream that was
+    current on the constructing thread), which is what ``synchronize()`` and ``allgather_returns()`` use as well.
+    The one-process-per-GPU form (``weak_shard`` + ``torch.distributed``) is what ``bench.py`` uses; this class is for
+    callers that do not want a launcher."""
+
+    def __init__(self, n_per_gpu: int, devices=None, seed: int = 0, threads: bool = True, streams=None, **engine_kwargs):
+        from concurrent.futures import ThreadPoolExecutor
         from . import _lib
         from .batched import Batched2048
         if devices is None:
@@ -108,46 +115,80 @@ class LocalShards:
         self.n_per_gpu = int(n_per_gpu)
         self.engines = [Batched2048(self.n_per_gpu, device=d, seed=seed, board_offset=r * self.n_per_gpu, **engine_kwargs)
                         for r, d in enumerate(self.devices)]
+        # torch's "current stream" is per thread: the workers must launch on the streams the caller sees
+        self.streams = list(streams) if streams is not None else [torch.cuda.current_stream(e.device) for e in self.engines]
+        if len(self.streams) != len(self.engines) or any(s.device != e.device for s, e in zip(self.streams, self.engines)):
+            raise ValueError("streams: one torch.cuda.Stream per engine, on that engine's device")
+        self._pools = [ThreadPoolExecutor(1, thread_name_prefix=f"g2048-dev{d}") for d in self.devices] if threads else None
+        self.issue_windows = [(0.0, 0.0)] * len(self.engines)    # host (start, end) of each engine's part of the last call
         self._lib = _lib.load()
-        self._comm = C.c_void_p()
-        arr = (C.c_int * len(self.devices))(*self.devices)
-        _lib.check(self._lib.g2048_comm_local_create(arr, len(self.devices), C.byref(self._comm)))
+        self._comm = None                              # the communicator set is built by the first all-gather
 
     @property
     def n_global(self) -> int:
         return self.n_per_gpu * len(self.engines)
 
+    def _each(self, fn):
+        """``fn(r, engine)`` for every engine, each on its own device thread and stream; returns when all calls have
+        RETURNED (= everything is enqueued; the devices keep running).  The first exception is re-raised."""
+        import time
+
+        def on_device(r):
+            t0 = time.perf_counter()
+            with torch.cuda.stream(self.streams[r]):
+                out = fn(r, self.engines[r])
+            self.issue_windows[r] = (t0, time.perf_counter())
+            return out
+        if self._pools is None:                       # threads=False: the serial form (tests compare the two)
+            return [on_device(r) for r in range(len(self.engines))]
+        futures = [pool.submit(on_device, r) for r, pool in enumerate(self._pools)]
+        return [f.result() for f in futures]
+
     def reset(self, seed=None):
-        for e in self.engines:
-            e.reset(seed=seed)
+        self._each(lambda r, e: e.reset(seed=seed))
 
     def rollout_random(self, k_steps: int):
-        for e in self.engines:                      # launches only: the devices run concurrently
-            e.rollout_random(k_steps)
+        self._each(lambda r, e: e.rollout_random(k_steps))
 
     def rollout(self, actions, **buffers):
         """``actions`` (and every optional ``[k, n]`` buffer): one tensor per device, on that device."""
-        for r, e in enumerate(self.engines):
-            e.rollout(actions[r], **{name: buf[r] for name, buf in buffers.items() if buf is not None})
+        self._each(lambda r, e: e.rollout(actions[r], **{name: buf[r] for name, buf in buffers.items() if buf is not None}))
+
+    def prepare_rollout(self, actions, **buffers):
+        """Validated per-device launch descriptors (``Batched2048.prepare_rollout``); ``run_plans`` issues them."""
+        return [e.prepare_rollout(actions[r], **{name: buf[r] for name, buf in buffers.items() if buf is not None})
+                for r, e in enumerate(self.engines)]
+
+    def run_plans(self, plans):
+        self._each(lambda r, e: plans[r].run())
 
     def allgather_returns(self):
         """Every device's copy of all ``n_global`` last episodic returns (int32), in global board order.  Enqueued on
-        the devices' current streams; ``synchronize()`` (or using the tensors on those streams) waits for it."""
+        the devices' streams (``self.streams``) from the caller's thread -- one grouped RCCL call must come from one
+        thread; ``synchronize()`` (or using the tensors on those streams) waits for it."""
         import ctypes as C
         from . import _lib
         g = len(self.engines)
+        if self._comm is None:                         # ncclCommInitAll: hundreds of milliseconds, ONCE
+            comm = C.c_void_p()
+            _lib.check(self._lib.g2048_comm_local_create((C.c_int * g)(*self.devices), g, C.byref(comm)))
+            self._comm = comm
         outs = [torch.empty(self.n_global, dtype=torch.int32, device=e.device) for e in self.engines]
         eng = (C.c_void_p * g)(*[e._h for e in self.engines])
         ptrs = (C.c_void_p * g)(*[o.data_ptr() for o in outs])
-        streams = (C.c_void_p * g)(*[torch.cuda.current_stream(e.device).cuda_stream for e in self.engines])
+        streams = (C.c_void_p * g)(*[s.cuda_stream for s in self.streams])
         _lib.check(self._lib.g2048_allgather_returns_local(self._comm, eng, ptrs, streams))
         return outs
 
     def synchronize(self):
-        for e in self.engines:
-            torch.cuda.synchronize(e.device)
+        for s in self.streams:
+            s.synchronize()
 
     def close(self):
+        if getattr(self, "_pools", None):
+            for pool in self._pools:
+                pool.shutdown(wait=True)
+            self._pools = None
         if getattr(self, "_comm", None):
             self._lib.g2048_comm_local_destroy(self._comm)
             self._comm = None

@@ -249,6 +249,44 @@ def test_local_shards_single_process_form(torch_cuda):
     sh.close()
 
 
+def test_local_shards_one_launch_thread_per_device(torch_cuda):
+    """SURVEY 8e's scaling risk -- a serial host loop over the devices delays the last device's first kernel by all
+    the launches issued before it.  LocalShards gives every engine its own launch thread: with two engines (both on
+    the one GPU there is, each on its own stream) the two launch trains are ISSUED concurrently (their host windows
+    overlap; in the serial form engine 1 starts when engine 0's train has been issued), and the games are the same."""
+    torch = torch_cuda
+    from gym2048_amd import LocalShards
+    n, seed, k = 1 << 14, 9, 1500
+    runs = {}
+    for threaded in (False, True):
+        streams = [torch.cuda.Stream(device=0), torch.cuda.Stream(device=0)]
+        sh = LocalShards(n, devices=[0, 0], seed=seed, threads=threaded, streams=streams)
+        sh.reset()
+        acts = [e.random_actions(k) for e in sh.engines]
+        rew = [torch.zeros((k, n), dtype=torch.float32, device="cuda:0") for _ in sh.engines]
+        term = [torch.zeros((k, n), dtype=torch.uint8, device="cuda:0") for _ in sh.engines]
+        torch.cuda.synchronize()
+        plans = sh.prepare_rollout(acts, reward=rew, terminated=term)
+        sh.run_plans(plans)                              # k launches per engine
+        (a0, b0), (a1, b1) = sh.issue_windows
+        sh.synchronize()
+        runs[threaded] = dict(boards=[e.get_boards() for e in sh.engines], rew=[r.cpu() for r in rew],
+                              term=[t.cpu() for t in term], stats=[e.episode_stats() for e in sh.engines],
+                              overlap=min(b0, b1) - max(a0, a1), span=max(b0, b1) - min(a0, a1), w=(a0, b0, a1, b1))
+        with pytest.raises(Exception):                   # one communicator per DEVICE: two engines on cuda:0 cannot gather
+            sh.allgather_returns()
+        sh.close()
+    ser, thr = runs[False], runs[True]
+    assert ser["overlap"] <= 0, ser["w"]                  # serial form: engine 1's train is issued after engine 0's
+    assert thr["overlap"] > 0.5 * min(thr["w"][1] - thr["w"][0], thr["w"][3] - thr["w"][2]), thr["w"]   # concurrent issue
+    print(f"issue span for 2 x {k} launches: serial {ser['span'] * 1e3:.2f} ms, one thread per engine {thr['span'] * 1e3:.2f} ms")
+    for r in range(2):
+        assert np.array_equal(ser["boards"][r], thr["boards"][r]) and ser["stats"][r] == thr["stats"][r]
+        assert torch.equal(ser["rew"][r], thr["rew"][r]) and torch.equal(ser["term"][r], thr["term"][r])
+    # and engine 1 (global boards n .. 2n-1) is not a copy of engine 0
+    assert not np.array_equal(thr["boards"][0], thr["boards"][1])
+
+
 def test_misaligned_buffers_are_refused(torch_cuda):
     torch = torch_cuda
     from gym2048_amd import _lib
