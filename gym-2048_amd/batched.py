@@ -99,6 +99,11 @@ class Batched2048:
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            # the host-resident views alias pinned memory that g2048_destroy frees: drop them first, so that a stale
+            # reference fails as "engine is closed" instead of reading unmapped memory
+            self._host_io = None
+            self._step_host_fn = self._fetch_host_fn = None
+            self._boards_view = None
             self._lib.g2048_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -422,12 +427,27 @@ class Batched2048:
         self.rng_mode = state.get("rng_mode", "philox")
 
     # ------------------------------------------------------------------ host-resident I/O
+    def stream_signal(self) -> int:
+        """Enqueue a completion ticket behind everything already enqueued on the current stream (one-wave kernel that
+        publishes the ticket to the engine's pinned completion word); ``stream_wait(ticket)`` then returns when the device
+        has got there -- the host polls the word, no runtime synchronisation call (``g2048_stream_signal`` / ``_wait``)."""
+        t = C.c_uint64()
+        check(self._lib.g2048_stream_signal(self._h, self._stream(), C.byref(t)))
+        return t.value
+
+    def stream_wait(self, ticket: int):
+        rc = self._lib.g2048_stream_wait(self._h, int(ticket), self._stream())
+        if rc:
+            check(rc)
+
     def host_io(self) -> dict:
         """numpy views of the engine's pinned, device-mapped host block (``g2048_host_io``): ``actions`` int64[n]
         (IN), ``reward`` float32[n], ``terminated`` / ``illegal`` / ``highest`` uint8[n], ``boards`` and
         ``terminal_boards`` uint8[n,4,4], ``scores`` int32[n].  ``step_host`` / ``fetch_host`` fill them in place.
         The views alias engine-owned memory: they are valid until ``close()`` (copy what must outlive the engine)."""
         if getattr(self, "_host_io", None) is None:
+            if not self._h:
+                raise G2048Error("engine is closed")
             raw = HostIO()
             check(self._lib.g2048_host_io_map(self._h, C.byref(raw)))
             n = self.n_envs
@@ -449,6 +469,8 @@ class Batched2048:
         them across the bus and writes every output into the views, and the call returns when they are there (the
         host polls a completion word: no staging copy, no stream synchronisation).  Returns the same dict."""
         io = self.host_io()
+        if not self._h:
+            raise G2048Error("engine is closed")
         rc = self._step_host_fn(self._h, 1 if auto_reset else 0, self._stream())
         if rc:
             check(rc)
@@ -458,6 +480,8 @@ class Batched2048:
     def fetch_host(self) -> dict:
         """Current boards and scores into the host views (after reset / set_boards / add_tile / move)."""
         io = self.host_io()
+        if not self._h:
+            raise G2048Error("engine is closed")
         check(self._fetch_host_fn(self._h, self._stream()))
         return io
 

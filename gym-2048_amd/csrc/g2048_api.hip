@@ -9,11 +9,15 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
-#include <immintrin.h>
 #include <mutex>
 #include <new>
+#include <thread>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -58,7 +62,8 @@ struct g2048_engine {
     void *host_base = nullptr;
     g2048_host_io host_io{};          // host addresses handed to the caller
     g2048_host_io host_io_dev{};      // the same arrays as the device sees them
-    unsigned long long *done_host = nullptr, *done_dev = nullptr; // completion word, polled by the host
+    // completion word (its own 64-byte pinned, device-mapped, coherent block): published by the device, polled by the host
+    unsigned long long *done_host = nullptr, *done_dev = nullptr;
     unsigned long long done_count = 0;
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
@@ -144,7 +149,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 9; }
+int g2048_abi_version(void) { return 10; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -222,6 +227,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipFree(e->returns);
         if (e->host_base)
             (void)hipHostFree(e->host_base);
+        if (e->done_host)
+            (void)hipHostFree(e->done_host);
         if (e->stats_partials)
             (void)hipFree(e->stats_partials);
         err = hipFree(e->slab);
@@ -488,15 +495,36 @@ static int copy_in(g2048_engine *e, void *dst, const void *src, size_t bytes, vo
 }
 
 // ------------------------------------------------------------------------- host-resident I/O
+static int ensure_done_word(g2048_engine *e)
+{
+    if (e->done_host)
+        return G2048_OK;
+    void *host = nullptr, *dev = nullptr;
+    hipError_t err = hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (err != hipSuccess)
+        return fail(G2048_ERR_NOMEM, "hipHostMalloc(64) for the completion word failed: %s", hipGetErrorString(err));
+    err = hipHostGetDevicePointer(&dev, host, 0);
+    if (err != hipSuccess) {
+        (void)hipHostFree(host);
+        return fail(G2048_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(err));
+    }
+    std::memset(host, 0, 64);
+    e->done_host = static_cast<unsigned long long *>(host);
+    e->done_dev = static_cast<unsigned long long *>(dev);
+    return G2048_OK;
+}
+
 static int ensure_host_io(g2048_engine *e)
 {
+    if (int rc = ensure_done_word(e))
+        return rc;
     if (e->host_base)
         return G2048_OK;
     const size_t n = e->n;
     auto up = [](size_t x) { return (x + 63) & ~static_cast<size_t>(63); };
     const size_t off_act = 0, off_rew = up(off_act + 8 * n), off_term = up(off_rew + 4 * n), off_ill = up(off_term + n),
                  off_high = up(off_ill + n), off_boards = up(off_high + n), off_tb = up(off_boards + 16 * n),
-                 off_sc = up(off_tb + 16 * n), off_done = up(off_sc + 4 * n), bytes = off_done + 64;
+                 off_sc = up(off_tb + 16 * n), bytes = up(off_sc + 4 * n);
     void *host = nullptr, *dev = nullptr;
     hipError_t err = hipHostMalloc(&host, bytes, hipHostMallocMapped | hipHostMallocCoherent);
     if (err != hipSuccess)
@@ -519,36 +547,73 @@ static int ensure_host_io(g2048_engine *e)
     };
     fill(e->host_io, static_cast<char *>(host));
     fill(e->host_io_dev, static_cast<char *>(dev));
-    e->done_host = reinterpret_cast<unsigned long long *>(static_cast<char *>(host) + off_done);
-    e->done_dev = reinterpret_cast<unsigned long long *>(static_cast<char *>(dev) + off_done);
     e->host_base = host;
     return G2048_OK;
 }
 
-// Poll the completion word (written by the device with system-scope release) until it shows `want`.
+// A launch whose completion the host will POLL for must really execute: on a capturing stream it would only be
+// recorded and the poll would never end.
+static int refuse_capture(hipStream_t s, const char *what)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return G2048_OK; // cannot tell (e.g. legacy stream semantics): go on
+    }
+    if (st != hipStreamCaptureStatusNone)
+        return fail(G2048_ERR_INVALID, "%s blocks until the device has finished; it cannot be used on a capturing stream", what);
+    return G2048_OK;
+}
+
+static inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    _mm_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+static double wait_limit_seconds()
+{
+    static const double limit = [] {
+        const char *v = std::getenv("G2048_WAIT_TIMEOUT_S");
+        const double x = v ? std::atof(v) : 0.0;
+        return x > 0.0 ? x : 120.0;
+    }();
+    return limit;
+}
+
+// Poll the completion word (published by the device with system-scope release; tickets on one stream only grow) until
+// it reaches `want`.  Liveness: after ~2 s without the word the stream is queried every ~2 s -- a failed stream ends the
+// wait with its error, a stream that has drained without publishing is a bug and says so -- and an overall deadline
+// (G2048_WAIT_TIMEOUT_S, default 120 s) returns an error instead of spinning forever on a hung device.
 static int wait_done(g2048_engine *e, unsigned long long want, hipStream_t s)
 {
     using clock = std::chrono::steady_clock;
-    clock::time_point last_check{};
+    clock::time_point started{}, last_check{};
     bool armed = false;
     for (uint64_t spins = 0;; ++spins) {
-        if (__atomic_load_n(e->done_host, __ATOMIC_ACQUIRE) == want)
+        if (__atomic_load_n(e->done_host, __ATOMIC_ACQUIRE) >= want)
             return G2048_OK;
-        _mm_pause();
-        if ((spins & 0xfffffu) == 0xfffffu) { // every ~million polls: is the stream still alive?
+        cpu_relax();
+        if ((spins & 0xfffffu) == 0xfffffu) { // every ~million polls
             const clock::time_point now = clock::now();
             if (!armed) {
                 armed = true;
-                last_check = now;
+                started = last_check = now;
             } else if (now - last_check > std::chrono::seconds(2)) {
                 last_check = now;
                 const hipError_t q = hipStreamQuery(s);
                 if (q == hipSuccess) // everything on the stream has finished: the word must be there
-                    return __atomic_load_n(e->done_host, __ATOMIC_ACQUIRE) == want
+                    return __atomic_load_n(e->done_host, __ATOMIC_ACQUIRE) >= want
                                ? G2048_OK
                                : fail(G2048_ERR_HIP, "the device finished without publishing the completion word");
                 if (q != hipErrorNotReady)
-                    return fail(G2048_ERR_HIP, "stream failed while waiting for a host-resident step: %s", hipGetErrorString(q));
+                    return fail(G2048_ERR_HIP, "stream failed while the host was waiting for the device: %s", hipGetErrorString(q));
+                if (std::chrono::duration<double>(now - started).count() > wait_limit_seconds())
+                    return fail(G2048_ERR_HIP, "no completion after %.0f s (G2048_WAIT_TIMEOUT_S): the device looks hung",
+                                wait_limit_seconds());
             }
         }
     }
@@ -573,6 +638,8 @@ int g2048_step_host(g2048_engine *e, int auto_reset, void *stream)
         return fail(G2048_ERR_INVALID, "call g2048_host_io_map first (the actions are read from its buffer)");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = refuse_capture(s, "g2048_step_host"))
+        return rc;
     const g2048_host_io &d = e->host_io_dev;
     g2048_step_io io{};
     io.actions = d.actions;
@@ -607,10 +674,38 @@ int g2048_fetch_host(g2048_engine *e, void *stream)
         return fail(G2048_ERR_INVALID, "call g2048_host_io_map first");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = refuse_capture(s, "g2048_fetch_host"))
+        return rc;
     const unsigned long long want = ++e->done_count;
     G2048_HIP(g2048::launch_fetch(e->st.boards, static_cast<uint32_t>(e->n), reinterpret_cast<uint4 *>(e->host_io_dev.boards),
                                   e->host_io_dev.scores, e->done_dev, want, s));
     return wait_done(e, want, s);
+}
+
+int g2048_stream_signal(g2048_engine *e, void *stream, uint64_t *ticket)
+{
+    if (!e || !ticket)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = refuse_capture(s, "g2048_stream_signal"))
+        return rc;
+    if (int rc = ensure_done_word(e))
+        return rc;
+    const unsigned long long want = ++e->done_count;
+    G2048_HIP(g2048::launch_signal(e->done_dev, want, s));
+    *ticket = want;
+    return G2048_OK;
+}
+
+int g2048_stream_wait(g2048_engine *e, uint64_t ticket, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (!e->done_host || ticket == 0 || ticket > e->done_count)
+        return fail(G2048_ERR_INVALID, "ticket %llu was not issued by g2048_stream_signal on this engine",
+                    (unsigned long long)ticket);
+    return wait_done(e, ticket, static_cast<hipStream_t>(stream));
 }
 
 // Is p device-accessible memory of this process (hipMalloc / torch tensor)?  Plain host memory is not
@@ -651,17 +746,48 @@ static int ensure_returns(g2048_engine *e)
     return G2048_OK;
 }
 
-// The device a pointer lives on (engine-less entry points launch there, whatever the caller's current device is).
-static int set_device_of(const void *p)
-{
-    hipPointerAttribute_t attr{};
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(G2048_ERR_INVALID, "buffer %p is not device memory of this process", p);
+// Engine-less entry points (g2048_augment, g2048_canonicalize) launch on the device their buffers live on, whatever
+// the caller's current device is, and put the caller's device back when they return.  Every buffer must be reachable
+// from that one device: device or managed memory OF that device, or pinned / registered host memory (which has a
+// device address everywhere).  Plain pageable host memory is refused.
+struct DeviceScope {
+    int previous = -1;
+    ~DeviceScope()
+    {
+        if (previous >= 0)
+            (void)hipSetDevice(previous);
     }
-    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
-        return fail(G2048_ERR_INVALID, "buffer %p is not device memory", p);
-    G2048_HIP(hipSetDevice(attr.device));
+};
+
+static int enter_device_of(DeviceScope &scope, const void *const *bufs, int n_bufs)
+{
+    int target = -1;
+    for (int k = 0; k < n_bufs; ++k) {
+        if (!bufs[k])
+            continue;
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, bufs[k]) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(G2048_ERR_INVALID, "buffer %p is not memory the device can reach (pageable host memory?)", bufs[k]);
+        }
+        if (attr.type == hipMemoryTypeHost) {
+            if (!attr.devicePointer)
+                return fail(G2048_ERR_INVALID, "host buffer %p has no device address (allocate it pinned and mapped)", bufs[k]);
+            continue; // reachable from every device
+        }
+        if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+            return fail(G2048_ERR_INVALID, "buffer %p is not device-accessible memory", bufs[k]);
+        if (target < 0)
+            target = attr.device;
+        else if (attr.device != target)
+            return fail(G2048_ERR_INVALID, "buffers live on different devices (%d and %d)", target, attr.device);
+    }
+    int current = 0;
+    G2048_HIP(hipGetDevice(&current));
+    if (target >= 0 && target != current) {
+        G2048_HIP(hipSetDevice(target));
+        scope.previous = current;
+    }
     return G2048_OK;
 }
 
@@ -884,7 +1010,9 @@ int g2048_augment(const uint8_t *boards, const uint8_t *next_boards, const uint8
         return fail(G2048_ERR_INVALID, "n too large");
     if (n == 0)
         return G2048_OK;
-    if (int rc = set_device_of(boards))
+    DeviceScope scope;
+    const void *bufs[] = {boards, next_boards, actions, boards_out, next_out, actions_out};
+    if (int rc = enter_device_of(scope, bufs, 6))
         return rc;
     G2048_HIP(g2048::launch_augment(reinterpret_cast<const uint4 *>(boards), reinterpret_cast<const uint4 *>(next_boards),
                                     actions, static_cast<uint32_t>(n), reinterpret_cast<uint4 *>(boards_out),
@@ -955,7 +1083,9 @@ int g2048_canonicalize(uint8_t *boards, uint8_t *next_boards, uint8_t *actions, 
         return fail(G2048_ERR_INVALID, "board buffers must be 16-byte aligned");
     if (n == 0)
         return G2048_OK;
-    if (int rc = set_device_of(boards))
+    DeviceScope scope;
+    const void *bufs[] = {boards, next_boards, actions, symmetry_out};
+    if (int rc = enter_device_of(scope, bufs, 4))
         return rc;
     G2048_HIP(g2048::launch_canonicalize(reinterpret_cast<uint4 *>(boards), reinterpret_cast<uint4 *>(next_boards), actions,
                                          static_cast<uint32_t>(n), symmetry_out, static_cast<hipStream_t>(stream)));

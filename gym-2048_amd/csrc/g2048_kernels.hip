@@ -202,18 +202,28 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 // lost on the compute side.
 constexpr uint32_t kObsOccupancyPad = 58u * 1024u;
 
-// dynamic LDS above 48 KiB is opt-in per kernel and per device
+// The pad plus the kernel's static LDS (the per-wave tables and the parked records) must fit the 64 KiB a workgroup may
+// own; two such workgroups then fill 128 of the CU's 160 KiB and a third does not fit.
+static_assert(sizeof(WaveTables) * (kBlock / 64) + sizeof(uint4) * kBlock + kObsOccupancyPad <= 64u * 1024u,
+              "static LDS + occupancy pad exceed the 64 KiB workgroup limit");
+
+// Dynamic LDS above 48 KiB is opt-in per kernel and per device.  Returns the pad to launch with: kObsOccupancyPad where
+// the device granted it, 0 where it did not (a part with less LDS, a runtime that refuses) -- the kernel is then merely
+// not occupancy-capped, instead of every observation-writing launch failing.
 template <class Kernel>
-static void allow_obs_pad(Kernel kernel, bool (&done)[64])
+static uint32_t obs_pad_for(Kernel kernel, signed char (&state)[64])
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         dev = 0;
-    if (done[dev])
-        return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(kObsOccupancyPad));
-    done[dev] = true;
+    if (state[dev] == 0) {
+        const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   static_cast<int>(kObsOccupancyPad));
+        if (err != hipSuccess)
+            (void)hipGetLastError(); // not sticky: the launch below goes ahead without the pad
+        state[dev] = err == hipSuccess ? 1 : -1;
+    }
+    return state[dev] > 0 ? kObsOccupancyPad : 0u;
 }
 
 template <int OBS, bool FULL>
@@ -1137,11 +1147,12 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
                         a.auto_reset, a.obs, a.obs_dtype, a.boards_out, a.done_seq, a.done_value};
 #define G2048_STEP_LAUNCH(ACT, FULL, STD, OBS)                                                                          \
     do {                                                                                                                \
+        uint32_t pad = 0u;                                                                                              \
         if (OBS) {                                                                                                      \
-            static bool pad_allowed[64] = {};                                                                           \
-            allow_obs_pad(&step_kernel<ACT, FULL, STD, OBS>, pad_allowed);                                              \
+            static signed char pad_state[64] = {};                                                                      \
+            pad = obs_pad_for(&step_kernel<ACT, FULL, STD, OBS>, pad_state);                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, (OBS) ? kObsOccupancyPad : 0u, s, a.st.boards,     \
+        hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, pad, s, a.st.boards,                               \
                            a.actions, a.st.ep_counters, a.board_offset, a.seed_lo, a.seed_hi, a.t_lo, a.t_hi, a.n,      \
                            a.reward, tail);                                                                             \
     } while (0)

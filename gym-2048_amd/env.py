@@ -40,6 +40,7 @@ def stack(flat, layers=15):
     return (flat[np.newaxis, :, :] == targets[:, np.newaxis, np.newaxis]).astype(int)
 
 
+_M64 = (1 << 64) - 1
 _CHANNELS = np.arange(16, dtype=np.uint8).reshape(16, 1, 1)
 _TILE_VALUES = np.array([0] + [1 << e for e in range(1, 32)], dtype=np.int64)   # exponent -> tile value
 
@@ -77,6 +78,22 @@ def _values_to_exp(v):
     return out
 
 
+class SpawnStreamRNG:
+    """What ``env.np_random`` is in the default RNG mode: the engine owns the randomness (the spawn stream of
+    include/g2048.h, one Philox block per board and step, no generator object anywhere), so there is nothing for a
+    caller to draw from.  Any use says so instead of silently handing out numbers the env will never consume."""
+
+    _MESSAGE = ("the HIP engine owns the spawn stream (include/g2048.h): env.np_random is not what add_tile() draws "
+                "from.  Construct the env with rng='numpy' for the reference's own numpy PCG64 generator "
+                "(game2048_env.py:103,168,170), or use reset(seed=...) to restart the spawn stream.")
+
+    def __getattr__(self, name):
+        raise AttributeError(f"np_random.{name}: {self._MESSAGE}")
+
+    def __repr__(self):
+        return "<SpawnStreamRNG: the engine owns the spawn stream; rng='numpy' gives a numpy Generator>"
+
+
 class Game2048Env(_env_base()):
     metadata = {"render_modes": ["ansi", "human", "rgb_array"], "render_fps": 4}  # game2048_env.py:35
     _all_positions = [(r, c) for r in range(4) for c in range(4)]                  # game2048_env.py:36
@@ -89,6 +106,7 @@ class Game2048Env(_env_base()):
         self.squares = self.size * self.size
         self.score = 0
         self.action_space, self.observation_space = make_spaces()
+        self._owns_engine = engine is None
         if engine is None:
             from .batched import Batched2048
             engine = Batched2048(1, device=device, seed=int.from_bytes(os.urandom(7), "little"), rng=rng)
@@ -132,10 +150,8 @@ class Game2048Env(_env_base()):
             reward = float(io["reward"][0])
             self.score += reward
             self._slot = 1
-        cells = io["boards"][0]
         info["highest"] = _TILE_VALUES[io["highest"][0]]   # :97 np.max(self.Matrix), an np.int64
-        self._cells = cells
-        return _stack_exp(cells), reward, bool(io["terminated"][0]), False, info
+        return _stack_exp(io["boards"][0]), reward, bool(io["terminated"][0]), False, info
 
     def reset(self, seed=None, options=None):
         """game2048_env.py:102-111."""
@@ -156,7 +172,35 @@ class Game2048Env(_env_base()):
         return render_board(self.Matrix, self.score, mode)
 
     def close(self):
-        pass
+        """Drops the views of the engine's pinned host block (they die with the engine) and closes an engine this env
+        created itself; an engine that was passed in stays the caller's."""
+        self._io = None
+        if self._owns_engine and self._eng is not None:
+            self._eng.close()
+        if self._scratch is not None:
+            self._scratch.close()
+            self._scratch = None
+
+    # ------------------------------------------------------------------ np_random (game2048_env.py:103,168,170)
+    @property
+    def np_random(self):
+        """The attribute the reference draws from.  ``rng='numpy'``: a ``numpy.random.Generator`` holding the CURRENT
+        state of this board's PCG64 on the device -- a snapshot (drawing from it does not advance the engine; assign a
+        generator to install its state).  Default mode: a ``SpawnStreamRNG`` whose every use raises with the reason."""
+        if getattr(self._eng, "rng_mode", "philox") == "numpy":
+            from .seeding import planes_to_generators
+            return planes_to_generators(self._eng.get_numpy_rng())[0]
+        return SpawnStreamRNG()
+
+    @np_random.setter
+    def np_random(self, generator):
+        bg = getattr(generator, "bit_generator", None)
+        st = getattr(bg, "state", None)
+        if not isinstance(st, dict) or st.get("bit_generator") != "PCG64":
+            raise TypeError("np_random must be a numpy.random.Generator over PCG64 (what gymnasium's seeding creates)")
+        planes = np.array([[st["state"]["state"] & _M64], [st["state"]["state"] >> 64], [st["state"]["inc"] & _M64],
+                           [st["state"]["inc"] >> 64], [st["uinteger"] | (st["has_uint32"] << 32)]], dtype=np.uint64)
+        self._eng.set_numpy_rng(planes)     # switches the engine to the numpy-compatible RNG mode
 
     @property
     def unwrapped(self):

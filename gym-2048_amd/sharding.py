@@ -49,7 +49,15 @@ def allgather_returns(local_returns: torch.Tensor, shard: Shard) -> torch.Tensor
     pad to the largest shard first.
     """
     if not dist.is_initialized():               # no process group: nothing to exchange
-        return local_returns.clone()            # (a ONE-rank group still runs the collective: bench.py's forced-dist mode)
+        return local_returns.clone()
+    if dist.get_world_size() != shard.world_size:
+        # the collective is over the WHOLE default group: a shard description for another world size would make the
+        # ranks disagree about the output size (or leave the others waiting).  A one-rank shard inside a larger job
+        # has nothing to exchange; anything else is a caller error.
+        if shard.world_size == 1:
+            return local_returns.clone()
+        raise ValueError(f"shard.world_size = {shard.world_size} but the process group has {dist.get_world_size()} ranks")
+    # (a ONE-rank group with a one-rank shard still runs the collective: bench.py's forced-dist mode)
     base, extra = divmod(shard.n_global, shard.world_size)
     n_max = base + (1 if extra else 0)
     send = local_returns

@@ -167,6 +167,18 @@ int g2048_host_io_map(g2048_engine *e, g2048_host_io *out);
 int g2048_step_host(g2048_engine *e, int auto_reset, void *stream);
 int g2048_fetch_host(g2048_engine *e, void *stream);
 
+/* Host-visible completion WITHOUT a runtime synchronisation call -- the mechanism behind g2048_step_host, exported for
+ * callers that bracket their own launch trains (a Gymnasium step() returns to the host after every call,
+ * game2048_env.py:100; a rollout loop returns once per rollout).  g2048_stream_signal enqueues on `stream` a one-wave
+ * kernel that publishes a fresh ticket (monotonically increasing per engine) to the engine's completion word -- 8 bytes
+ * of pinned, device-mapped, coherent host memory -- with a system-scope release, i.e. after everything enqueued on
+ * `stream` before it has completed and is visible to the host.  g2048_stream_wait spins on that word until it reaches
+ * `ticket`: about 5 us less than hipStreamSynchronize per call on MI355X (tools/ubench/host_latency.hip,
+ * tail_probe.hip).  The wait checks the stream's health every ~2 s and gives up after G2048_WAIT_TIMEOUT_S (default
+ * 120) seconds; neither call may be used on a capturing stream.  Signals of one engine must be stream-ordered. */
+int g2048_stream_signal(g2048_engine *e, void *stream, uint64_t *ticket);
+int g2048_stream_wait(g2048_engine *e, uint64_t ticket, void *stream);
+
 /* k consecutive g2048_step launches without returning to the caller.  Buffers of step j are the
  * io pointers advanced by j * stride elements (stride = 0 reuses the same buffers, stride = n
  * walks [k][n] rollout buffers; an element of obs is one board's whole [16][4][4] observation). */

@@ -37,6 +37,13 @@ class OracleEngine:
     def close(self):
         pass
 
+    def get_numpy_rng(self):
+        return np.ascontiguousarray(self.ob.rng.T)          # uint64 [5, n], as Batched2048.get_numpy_rng
+
+    def set_numpy_rng(self, planes):
+        self.ob.rng = np.ascontiguousarray(np.asarray(planes, dtype=np.uint64).T)
+        self.rng_mode = "numpy"
+
     # reset / step
     def reset(self, seed=None, first_slot=0, new_transaction=None, mask=None):
         if seed is not None:

@@ -1,6 +1,7 @@
 """CPU, world_size = 2 over gloo: the multi-GPU layout (one process per shard, global-index RNG, one
 all-gather of episodic returns per rollout) with the oracle standing in for the per-rank engine.
 On the GPU box the same sharding helpers run over RCCL (bench.py --gpus N)."""
+import ctypes as C
 import os
 import socket
 import sys
@@ -42,7 +43,15 @@ def _worker(rank, world, port, n_global, steps, seed, out_dir):
         for k, v in enumerate(np.bincount(ob.boards.max(axis=1), minlength=32)):
             st.highest_hist[k] = int(v)
         rows = allgather_stats(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
-        assert rows.shape == (world, 168)
+        assert rows.shape == (world, C.sizeof(Stats))
+        # a shard description that does not belong to this process group: a one-rank shard has nothing to exchange
+        # (no collective is entered, so no rank is left waiting); any other mismatch is refused before the collective
+        from gym2048_amd.sharding import Shard
+        mine = torch.arange(5, dtype=torch.int32) + rank
+        alone = allgather_returns(mine, Shard(0, 1, 5, 0, 5))
+        assert torch.equal(alone, mine) and alone.data_ptr() != mine.data_ptr()
+        with pytest.raises(ValueError, match="process group has"):
+            allgather_returns(mine, shard_range(5 * (world + 1), 0, world + 1))
         summ = merge_stats(rows)
         if rank == 0:
             np.savez(os.path.join(out_dir, "gathered.npz"), returns=returns.numpy(), boards=boards.numpy(),

@@ -178,6 +178,48 @@ def test_canonicalize_vs_reference_table_and_oracle(torch_cuda):
                              np.zeros(8 * 64, np.uint8).ctypes.data, None) == -1
 
 
+def test_engine_less_entry_points_accept_pinned_host_buffers_and_keep_the_device(torch_cuda):
+    """g2048_augment / g2048_canonicalize need no engine: they launch on the device their buffers live on, accept
+    pinned (device-mapped) host memory next to device memory, refuse pageable host memory with a message, and leave
+    the caller's current device as it was."""
+    import ctypes as C
+    torch = torch_cuda
+    from gym2048_amd import _lib
+    lib = _lib.load()
+    n = 512
+    rs = np.random.default_rng(3)
+    boards = rs.integers(0, 12, (n, 16)).astype(np.uint8)
+    acts = rs.integers(0, 4, n).astype(np.uint8)
+    dev_b, dev_a = torch.as_tensor(boards).cuda(), torch.as_tensor(acts).cuda()
+    out_b = torch.zeros((8, n, 16), dtype=torch.uint8, device="cuda")
+    out_a = torch.zeros((8, n), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.g2048_augment(dev_b.data_ptr(), None, dev_a.data_ptr(), n, out_b.data_ptr(), None, out_a.data_ptr(), None))
+    torch.cuda.synchronize()
+    pin_b, pin_a = torch.as_tensor(boards).pin_memory(), torch.as_tensor(acts).pin_memory()
+    pout_b = torch.zeros((8, n, 16), dtype=torch.uint8).pin_memory()
+    pout_a = torch.zeros((8, n), dtype=torch.uint8).pin_memory()
+    before = torch.cuda.current_device()
+    _lib.check(lib.g2048_augment(pin_b.data_ptr(), None, pin_a.data_ptr(), n, pout_b.data_ptr(), None, pout_a.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before
+    assert torch.equal(pout_b, out_b.cpu()) and torch.equal(pout_a, out_a.cpu())
+    # mixed: pinned input, device output
+    out_b.zero_()
+    _lib.check(lib.g2048_augment(pin_b.data_ptr(), None, dev_a.data_ptr(), n, out_b.data_ptr(), None, out_a.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(pout_b, out_b.cpu())
+    pageable = np.ascontiguousarray(boards)
+    rc = lib.g2048_augment(pageable.ctypes.data, None, dev_a.data_ptr(), n, out_b.data_ptr(), None, out_a.data_ptr(), None)
+    assert rc != 0 and b"pageable" in lib.g2048_last_error()
+    canon = pin_b.clone().pin_memory()
+    _lib.check(lib.g2048_canonicalize(canon.data_ptr(), None, None, n, None, None))
+    torch.cuda.synchronize()
+    dcanon = dev_b.clone()
+    _lib.check(lib.g2048_canonicalize(dcanon.data_ptr(), None, None, n, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(canon, dcanon.cpu())
+
+
 def test_collective_behind_the_c_abi_one_rank(torch_cuda):
     """g2048_comm_* / g2048_allgather_returns with RCCL loaded by the library itself: a one-rank communicator
     (the degenerate case a 1-GPU box can run) gathers the engine's returns; the single-process multi-engine

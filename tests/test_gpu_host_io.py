@@ -135,3 +135,80 @@ def test_vec_env_one_launch_per_step_with_fused_observation(torch_cuda):
                     else:
                         assert x[key] == y[key]
         real.close()
+
+
+def test_stream_signal_wait_and_capture_refusal(torch_cuda):
+    """g2048_stream_signal / g2048_stream_wait: the completion word behind a launch train.  When the wait returns, every
+    output of the launches enqueued before the signal is visible to the host (checked through mapped host memory, with
+    no runtime synchronisation in between); tickets grow monotonically; an old ticket returns at once; a ticket that
+    was never issued and a capturing stream are refused (a poll on a captured -- never executed -- kernel would not end)."""
+    torch = torch_cuda
+    from gym2048_amd._lib import G2048Error
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, k = 1 << 16, 4, 24
+    eng, ora = Batched2048(n, seed=seed), OracleBatch(n, seed)
+    eng.reset()
+    ora.reset()
+    io = eng.host_io()                                      # the rollout's last rewards land in mapped host memory
+    acts = eng.random_actions(k)
+    rew = torch.zeros((k, n), dtype=torch.float32, device=eng.device)
+    tickets = []
+    for rep in range(3):
+        eng.rollout(acts if rep == 0 else k, reward=rew)
+        tickets.append(eng.stream_signal())
+        eng.stream_wait(tickets[-1])
+        assert torch.cuda.current_stream(eng.device).query()          # nothing left on the stream when the word arrived
+        for _ in range(k):
+            ora.step(None)
+        assert np.array_equal(rew[-1].cpu().numpy(), ora.reward)
+    assert tickets == sorted(tickets) and len(set(tickets)) == 3
+    eng.stream_wait(tickets[0])                             # already passed: returns at once
+    with pytest.raises(G2048Error, match="not issued"):
+        eng.stream_wait(tickets[-1] + 5)
+    # a capturing stream: signal, step_host and fetch_host refuse instead of spinning on a kernel that never runs
+    side = torch.cuda.Stream(device=eng.device)
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream(eng.device))
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        try:
+            with pytest.raises(G2048Error, match="capturing stream"):
+                eng.stream_signal()
+            with pytest.raises(G2048Error, match="capturing stream"):
+                eng.step_host()
+            with pytest.raises(G2048Error, match="capturing stream"):
+                eng.fetch_host()
+        finally:
+            graph.capture_end()
+    torch.cuda.synchronize()
+    assert io["boards"].shape == (n, 4, 4)
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards)     # the refused calls changed nothing
+
+
+def test_views_die_with_the_engine(torch_cuda):
+    """close(): the numpy views of the pinned host block are dropped before the block is freed, and the host-resident
+    calls of a closed engine raise instead of touching unmapped memory; Game2048Env.close() closes the engine it made."""
+    from gym2048_amd import Game2048Env
+    from gym2048_amd._lib import G2048Error
+    from gym2048_amd.batched import Batched2048
+    eng = Batched2048(64, seed=1)
+    eng.reset()
+    eng.host_io()["actions"][:] = 1
+    eng.step_host()
+    eng.close()
+    assert eng._host_io is None and eng._boards_view is None
+    for call in (eng.step_host, eng.fetch_host, eng.host_io):
+        with pytest.raises(G2048Error):
+            call()
+    env = Game2048Env()
+    env.reset(seed=3)
+    env.step(0)
+    env.close()
+    assert env._io is None and not env._eng._h
+    mine = Batched2048(1, seed=2)
+    env = Game2048Env(engine=mine)
+    env.reset(seed=2)
+    env.close()
+    assert mine._h and mine.host_io() is not None            # a caller's engine stays the caller's
+    mine.close()

@@ -356,3 +356,38 @@ def test_evaluate_model_reproduces_the_reference_evaluation_loop(tag, eps, tmp_p
     assert res["Max score"] == g[f"{tag}_total_reward"].max() and res["Highest tile"] == g[f"{tag}_highest"].max()
     name = report_evaluation_results(res, label=tag, path=str(tmp_path / f"scores_{tag}.csv"))
     assert open(name, "rb").read() == bytes(g[f"{tag}_csv"])                                  # train.py:216-229
+
+
+def test_np_random_attribute_without_gymnasium():
+    """Game2048Env.np_random (game2048_env.py:103,168,170; SURVEY 8b attribute list) exists whether or not gymnasium
+    is installed.  Default mode: the engine owns the spawn stream and any use of the attribute says so.  rng='numpy':
+    a real numpy Generator carrying the CURRENT state of the board's PCG64 -- what the reference's next add_tile() will
+    draw -- and assigning a generator installs its state."""
+    env = Game2048Env(engine=OracleEngine(1, 7))
+    env.reset(seed=7)
+    with pytest.raises(AttributeError, match="owns the spawn stream"):
+        env.np_random.random()
+    with pytest.raises(AttributeError, match="rng='numpy'"):
+        env.np_random.shuffle([1, 2, 3])
+    assert "SpawnStreamRNG" in repr(env.np_random)
+
+    env = Game2048Env(engine=OracleEngine(1, 42, rng="numpy"))
+    env.reset(seed=42)                                        # consumed exactly what the reference's reset(seed=42) consumes
+    want = np.random.Generator(np.random.PCG64(np.random.SeedSequence(42)))
+    for _ in range(2):                                        # reset() = two add_tile(): random() then shuffle(16 positions)
+        want.random()
+        want.shuffle(list(range(16)))
+    got = env.np_random
+    assert isinstance(got, np.random.Generator)
+    assert got.bit_generator.state == want.bit_generator.state
+    assert got.random() == want.random()                      # a snapshot: drawing from it ...
+    assert env.np_random.bit_generator.state != got.bit_generator.state     # ... does not advance the engine's generator
+    # installing a generator: the env then plays the reference's game for that generator
+    other = Game2048Env(engine=OracleEngine(1, 0))
+    other.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(42)))
+    other.reset()
+    assert np.array_equal(other.Matrix, env.Matrix)           # same first board as reset(seed=42)
+    with pytest.raises(TypeError):
+        other.np_random = np.random.Generator(np.random.MT19937(1))
+    env.close()
+    assert env._io is None
