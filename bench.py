@@ -319,7 +319,8 @@ def main():
 
     def gather_returns():
         """The path's only exchange, once per rollout: every rank reduces the episodic returns of its shard on
-        the device (one kernel pair, no host sync) and the per-rank summaries are all-gathered (RCCL over xGMI,
+        the device (one kernel pair, no host sync: episodes, illegal ends and the EXACT sum of the final scores of all
+        finished episodes, g2048_stats.return_sum) and the per-rank summaries are all-gathered (RCCL over xGMI,
         latency-bound); --gather full ships every board's last return instead (4 MiB per rank at 2^20).
         Everything is enqueued on the current stream into buffers allocated beforehand."""
         if args.gather == "full":
@@ -442,15 +443,19 @@ def main():
                    "note": "max over ranks; wall = launch train (K step launches, HIP events) + collective (statistics "
                            "kernel + all-gather, HIP events; 0 at N = 1) + host tail (launch-to-start latency and "
                            "end-to-host-visible latency of the closing bracket)"},
-        "episodes_finished": int(stats["episodes"]), "mean_last_episode_score": stats["mean_last_score"],
+        "episodes_finished": int(stats["episodes"]), "return_sum": int(stats["return_sum"]),
+        "mean_episode_score": stats["mean_episode_score"],        # exact: over ALL finished episodes of this rank's shard
+        "mean_last_episode_score": stats["mean_last_score"],      # over each board's most recent finished episode
     }
     if force_dist and world == 1:
         out["config"]["forced_dist"] = f"one-rank {backend} process group: the N > 1 code path on one GPU"
         out["config"]["collective"] = "one-rank all-gather of the episodic-return summary (forced)" 
     if gathered is not None and args.gather == "summary":
         g = merge_stats(gathered)
-        out["global_returns"] = {"episodes": g["episodes"], "mean_last_episode_score": g["mean_last_score"],
-                                 "best_last_episode_score": g["last_score_max"]}
+        out["global_returns"] = {"episodes": g["episodes"], "illegal_ends": g["illegal_ends"], "return_sum": g["return_sum"],
+                                 "mean_episode_score": g["mean_episode_score"],
+                                 "note": "from the all-gathered per-rank summaries: every finished episode of every rank since "
+                                         "the reset (g2048_stats.return_sum is exact)"}
 
     if rank == 0 and world == 1 and not args.no_extras and not force_dist:
         extras = {}

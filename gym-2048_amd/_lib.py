@@ -60,6 +60,7 @@ class Stats(C.Structure):
         ("last_score_max", C.c_int32),
         ("max_exp", C.c_uint32),
         ("highest_hist", C.c_uint32 * 32),
+        ("return_sum", C.c_int64),
     ]
 
 

@@ -391,16 +391,21 @@ class Batched2048:
 
     def episode_stats(self) -> dict:
         """Episode statistics since create/seed, reduced on the device: ``episodes`` / ``illegal_ends`` count
-        every finished episode; ``last_*`` describe each board's most recent finished episode."""
+        every finished episode, ``return_sum`` is the exact sum of their final merge scores (``mean_episode_score`` =
+        the mean; ``mean_episode_return`` adds the illegal-move rewards, i.e. what SB3's Monitor reports as the mean of
+        ``info["episode"]["r"]``, ppo_train.py:123); ``last_*`` describe each board's most recent finished episode."""
         st = Stats()
         check(self._lib.g2048_episode_stats(self._h, C.byref(st), self._stream()))
-        return parse_stats(bytes(st))
+        out = parse_stats(bytes(st))
+        out["mean_episode_return"] = ((out["return_sum"] + out["illegal_ends"] * self.illegal_move_reward) / out["episodes"]
+                                      if out["episodes"] else 0.0)
+        return out
 
     def episode_stats_device(self, out=None, returns_only: bool = False) -> torch.Tensor:
         """The same reduction as ``episode_stats`` left ON THE DEVICE: a ``uint8 [sizeof(g2048_stats)]`` tensor
         holding the C struct, enqueued on the current stream without a host sync (what a multi-GPU job
-        all-gathers once per rollout; decode with ``parse_stats``).  ``returns_only``: only the episode counters and
-        the returns of the boards' last episodes (``max_exp`` / ``highest_hist`` zero) -- the live boards are not read."""
+        all-gathers once per rollout; decode with ``parse_stats``).  ``returns_only``: only ``episodes``, ``illegal_ends``
+        and the exact ``return_sum`` (everything else zero) -- the terminal records are not read, no histogram."""
         nbytes = C.sizeof(Stats)
         if out is None:
             out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -634,7 +639,9 @@ def parse_stats(raw) -> dict:
     return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count,
                 last_score_sum=st.last_score_sum, last_score_max=st.last_score_max, max_exp=st.max_exp,
                 mean_last_score=(st.last_score_sum / st.last_count) if st.last_count else 0.0,
-                highest_hist=[int(x) for x in st.highest_hist])
+                highest_hist=[int(x) for x in st.highest_hist],
+                return_sum=st.return_sum,      # exact: final merge scores of ALL finished episodes
+                mean_episode_score=(st.return_sum / st.episodes) if st.episodes else 0.0)
 
 
 def exp_to_values(exps) -> np.ndarray:

@@ -39,7 +39,7 @@ int fail(int code, const char *fmt, ...)
             return fail(G2048_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(err_));                       \
     } while (0)
 
-constexpr uint64_t kStateMagic = 0x3276383430324700ull; // "\0G2048v2": records carry the score (layout 2)
+constexpr uint64_t kStateMagic = 0x3376383430324700ull; // "\0G2048v3": layout 3 = records carry the score, 4-word episode slots
 
 } // namespace
 
@@ -181,8 +181,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     const size_t off_boards = 0;
     const size_t off_last_record = off_boards + align_up(n * 16);
     const size_t off_counters = off_last_record + align_up(n * 16);
-    // two counters per 64 boards (whole 256-lane launch blocks)
-    const size_t n_counters = ((n + 255) / 256) * 8;
+    // one slot of kSlotWords counters per 64 boards (whole 256-lane launch blocks)
+    const size_t n_counters = ((n + 255) / 256) * 4 * g2048::kSlotWords;
     const size_t off_stats = off_counters + align_up(n_counters * sizeof(unsigned long long));
     e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
     err = hipMalloc(&e->slab, e->slab_bytes);
@@ -775,8 +775,8 @@ static int enter_device_of(DeviceScope &scope, const void *const *bufs, int n_bu
                 return fail(G2048_ERR_INVALID, "host buffer %p has no device address (allocate it pinned and mapped)", bufs[k]);
             continue; // reachable from every device
         }
-        if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
-            return fail(G2048_ERR_INVALID, "buffer %p is not device-accessible memory", bufs[k]);
+        if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) // e.g. hipMemoryTypeUnregistered
+            return fail(G2048_ERR_INVALID, "buffer %p is not memory the device can reach (pageable host memory?)", bufs[k]);
         if (target < 0)
             target = attr.device;
         else if (attr.device != target)
@@ -876,7 +876,7 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
     } else if (reinterpret_cast<uintptr_t>(buf) & 3u) {
         return fail(G2048_ERR_INVALID, "device score buffers must be 4-byte aligned");
     }
-    G2048_HIP(g2048::launch_import_scores(e->st.boards, n, src, s));
+    G2048_HIP(g2048::launch_import_scores(e->st.boards, n, src, e->st.ep_counters, s));
     if (src == e->scratch)
         G2048_HIP(hipStreamSynchronize(s));
     return G2048_OK;
@@ -923,6 +923,7 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
     out->max_exp = h.max_exp;
     for (int k = 0; k < 32; ++k)
         out->highest_hist[k] = h.highest_hist[k];
+    out->return_sum = h.return_sum;
     return G2048_OK;
 }
 

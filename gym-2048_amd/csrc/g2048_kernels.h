@@ -14,8 +14,10 @@ struct DeviceState {
                         //     array -- self.score (game2048_env.py:86) = potential - deficit
     uint4 *last_record; // [n] record a board's most recent episode ENDED on (all-zero: none yet); its score is
                         //     that episode's return.  Written only by lanes whose episode ended.
-    unsigned long long *ep_counters; // two per 64 boards: {finished episodes, of which ended on an illegal move},
-                                     // updated by ONE lane of a wavefront that finished episodes (old values via the scalar cache)
+    unsigned long long *ep_counters; // one SLOT of kSlotWords uint64 per 64 boards: {finished episodes, of which ended on an
+                                     // illegal move, G = summed merge scores (return accounting), pending mask}; updated by
+                                     // ONE lane of the wavefront that owns the boards (old values via the scalar cache);
+                                     // layout and meaning in g2048_kernels.hip "episode SLOT"
     uint64_t *rng;      // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
     // numpy-RNG mode only (same allocation, behind the planes): the boards whose episode ended in the current step,
     // one list of up to 64 local board indices per wavefront of the step launch + its length.  The step kernel
@@ -23,6 +25,8 @@ struct DeviceState {
     uint32_t *term_list;  // [ceil(n / 64)][64]
     uint32_t *term_count; // [ceil(n / 64)]
 };
+
+constexpr uint32_t kSlotWords = 4; // uint64 per wavefront slot of ep_counters
 
 // bytes of the numpy-RNG allocation for n boards: 5 planes of uint64, the lists, the counts
 inline size_t numpy_rng_bytes(uint64_t n)
@@ -62,6 +66,7 @@ struct StatsOut {
     int last_score_max;
     unsigned int max_exp;
     unsigned int highest_hist[32]; // boards whose highest tile is 2^k right now (game2048_env.py:190-192)
+    long long return_sum;          // sum of the final scores of ALL finished episodes (exact)
 };
 
 hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s);
@@ -86,14 +91,15 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
                           uint4 *boards_out, uint4 *next_out, uint8_t *actions_out, hipStream_t s);
 // partials: kStatsPartialWords uint64 of device scratch (stage 1 -> stage 2; field-major, one column per block)
 constexpr uint32_t kStatsBlocks = 2048;
-constexpr uint32_t kStatsPartialWords = (6 + 32) * kStatsBlocks;
+constexpr uint32_t kStatsPartialWords = (7 + 32) * kStatsBlocks;
 hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, bool returns_only,
                         hipStream_t s);
 // record <-> plain views (cells uint8[n][16], scores int32[n]); device pointers
 hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s);
 hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s);
 hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *scores_out, hipStream_t s); // also last_record -> returns
-hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, hipStream_t s);
+hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, unsigned long long *ep_counters,
+                                hipStream_t s);
 hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s);
 hipError_t launch_export_last_scores(const DeviceState &st, uint32_t n, int32_t *out, hipStream_t s);
 // host-resident I/O: boards + scores of the current state in one launch; the completion word (see StepArgs::done_seq)

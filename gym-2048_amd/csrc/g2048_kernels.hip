@@ -136,14 +136,15 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
 
 // Episode bookkeeping, shared by every step kernel.  A lane whose episode ended stores the record it
 // ended on (sparse 16-byte store; plain, not nt: L2 merges these into lines) and, if asked, the plain
-// terminal board; the wave's two counts go to its counter pair (flush_episode_counts).  Skipped
+// terminal board; the wave's two counts go to its slot (flush_episode_counts).  Skipped
 // entirely by a wave-uniform branch when no lane terminated.
-__device__ __forceinline__ void record_episode_ends(const StepArgs &p, uint32_t i, bool fin, bool illegal, const Board &terminal,
-                                                    uint32_t &episodes, uint32_t &illegal_ends)
+// Returns the lane mask of the boards whose episode ended in this step.
+__device__ __forceinline__ unsigned long long record_episode_ends(const StepArgs &p, uint32_t i, bool fin, bool illegal,
+                                                                  const Board &terminal, uint32_t &episodes, uint32_t &illegal_ends)
 {
     const unsigned long long done = __builtin_amdgcn_ballot_w64(fin);
     if (done == 0ull)
-        return;
+        return 0ull;
     if (fin) {
         store_board(p.st.last_record, i, terminal);
         if (p.terminal_boards)
@@ -151,33 +152,105 @@ __device__ __forceinline__ void record_episode_ends(const StepArgs &p, uint32_t 
     }
     episodes += static_cast<uint32_t>(__popcll(done));
     illegal_ends += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(fin && illegal)));
+    return done;
 }
 
-// The wave's counter pair is private to it (one wavefront per pair per launch, launches are
-// stream-ordered), so it is updated without atomics: the old values come in through the SCALAR cache
-// (uniform address, loaded at kernel entry -- no VALU, no vector-memory instruction, latency never
-// exposed) and ONE lane stores the sums when the wave finished episodes.  Measured against 64-bit
-// atomics: -0.5 us per launch at 2^20 boards (profiles/r02_g_ubench_2p20.txt).
+// ---- wave-wide sums.  gfx9 DPP: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of
+// rows 0 / 2 is added to rows 1 / 3 (row_bcast:15) and lane 31 to rows 2, 3 (row_bcast:31): six v_add_u32_dpp, the
+// wave's total ends up in LANE 63 (the other lanes hold partial sums).  Every lane of the wavefront must be active.
+__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t v)
+{
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false)); // row_shr:1
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false)); // row_shr:2
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false)); // row_shr:4
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false)); // row_shr:8
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false)); // row_bcast:15 -> rows 1, 3
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false)); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// The same for 64-bit lane values (the gains a lane accumulated over a fused rollout): three 22-bit pieces, each of
+// whose 64-lane sums fits 32 bits, recombined in lane 63.  Once per launch.
+__device__ __forceinline__ unsigned long long wave_sum64_lane63(unsigned long long v)
+{
+    const uint32_t s0 = wave_sum_lane63(static_cast<uint32_t>(v) & 0x3fffffu);
+    const uint32_t s1 = wave_sum_lane63(static_cast<uint32_t>(v >> 22) & 0x3fffffu);
+    const uint32_t s2 = wave_sum_lane63(static_cast<uint32_t>(v >> 44));
+    return static_cast<unsigned long long>(s0) + (static_cast<unsigned long long>(s1) << 22) +
+           (static_cast<unsigned long long>(s2) << 44);
+}
+
+// ---- the wavefront's episode SLOT: four uint64 per 64 boards (g2048_kernels.h kSlotWords)
+//   [0] episodes      finished episodes
+//   [1] illegal_ends  ... of which ended on an illegal move
+//   [2] gain_sum      G: merge score of every move of these 64 boards since the statistics were cleared (+ the scores
+//                     they held then, -/+ what g2048_reset / g2048_set_scores took away or put in).  Conservation:
+//                     every point scored is either still on a live board or belongs to a finished episode, so
+//                         sum of the final scores of ALL finished episodes  =  G - sum of the live boards' scores
+//                     which the statistics kernel evaluates (g2048_stats.return_sum) -- exact, and no per-episode
+//                     work in the step: the step only adds its 64 gains (six DPP adds)
+//   [3] pending       bit l: board l's episode has ended and the board has NOT been reset (auto_reset == 0): its score
+//                     belongs to a finished episode although it is still in the record
+// The slot is private to its wavefront (one wavefront per slot per launch, launches are stream-ordered), so it is
+// updated without atomics: the old values come in through the SCALAR cache (uniform address, loaded at kernel entry
+// -- no VALU, no vector-memory instruction, latency never exposed) and ONE lane -- lane 63, where the DPP sum of the
+// gains lands -- stores the new ones.  Measured against 64-bit atomics: -0.5 us per launch at 2^20 boards
+// (profiles/r02_g_ubench_2p20.txt).
 struct EpisodeCounters {
     unsigned long long *slot;
-    unsigned long long episodes, illegal_ends;
+    unsigned long long episodes, illegal_ends, gain_sum;
 };
 
 __device__ __forceinline__ EpisodeCounters load_episode_counters(const StepArgs &p, uint32_t i_raw)
 {
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(i_raw >> 6);
-    unsigned long long *slot = p.st.ep_counters + 2u * wave_id;
-    return EpisodeCounters{slot, slot[0], slot[1]};
+    unsigned long long *slot = p.st.ep_counters + kSlotWords * wave_id;
+    return EpisodeCounters{slot, slot[0], slot[1], slot[2]};
 }
 
-__device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, uint32_t episodes, uint32_t illegal_ends)
+// gain_lane63: the wave's summed merge score of this launch, valid in lane 63 (wave_sum_lane63 / wave_sum64_lane63);
+// pending: the new pending mask (wave-uniform).
+__device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, uint32_t episodes, uint32_t illegal_ends,
+                                                     unsigned long long gain_lane63, unsigned long long pending)
 {
-    if (episodes == 0u || (threadIdx.x & 63u) != 0u) // episodes is wave-uniform
+    if ((threadIdx.x & 63u) != 63u)
         return;
-    ulonglong2 v;
-    v.x = c.episodes + episodes;
+    ulonglong2 v, g;
+    v.x = c.episodes + episodes; // (wave-uniform: scalar adds)
     v.y = c.illegal_ends + illegal_ends;
+    g.x = c.gain_sum + gain_lane63;
+    g.y = pending;
     *reinterpret_cast<ulonglong2 *>(c.slot) = v;
+    *reinterpret_cast<ulonglong2 *>(c.slot + 2) = g;
+}
+
+// "episode ended and not reset" mask of a step launch from the mask of the lanes whose episode ended: every board was
+// stepped, so older marks are gone, and with auto_reset nothing stays pending.  Scalar arithmetic, no branch.
+__device__ __forceinline__ unsigned long long pending_after_step(unsigned long long done, uint32_t auto_reset)
+{
+    return done & (0ull - static_cast<unsigned long long>(auto_reset == 0u ? 1u : 0u));
+}
+
+// What a reset / score import does to the slot of its wavefront (not hot; whole wavefronts must call it):
+//   reset of a board whose episode is still running   -> the episode is ABANDONED: its score leaves G
+//   reset of a board whose episode has ended (pending) -> the mark is cleared, its score stays in G (a finished episode)
+// `delta`: signed change of the board's live score caused by this call (0 for lanes that do nothing), `clear`: the lane
+// clears its pending mark.
+__device__ __forceinline__ void adjust_slot(unsigned long long *ep_counters, uint32_t i_raw, int32_t delta, bool clear)
+{
+    const uint32_t total = wave_sum_lane63(static_cast<uint32_t>(delta)); // |sum| <= 64 * 2^24: fits int32
+    const unsigned long long cleared = __builtin_amdgcn_ballot_w64(clear);
+    if ((threadIdx.x & 63u) == 63u) {
+        unsigned long long *slot = ep_counters + kSlotWords * (i_raw >> 6);
+        slot[2] += static_cast<unsigned long long>(static_cast<long long>(static_cast<int32_t>(total)));
+        slot[3] &= ~cleared;
+    }
+}
+
+__device__ __forceinline__ bool is_pending(const unsigned long long *ep_counters, uint32_t i_raw)
+{
+    const unsigned long long pending = ep_counters[kSlotWords * __builtin_amdgcn_readfirstlane(i_raw >> 6) + 3u];
+    return ((pending >> (threadIdx.x & 63u)) & 1ull) != 0ull;
 }
 
 // ------------------------------------------------------------ observation fused into the step
@@ -362,7 +435,10 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
 
     // episode ends first: the terminal record goes out before the reset overwrites it in place
     uint32_t episodes = 0, illegal_ends = 0;
-    record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+    const unsigned long long done = record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+    // :86 self.score += score -- the wave's 64 gains go to its slot (G of the return accounting; an illegal move gains 0)
+    const uint32_t wave_gain = wave_sum_lane63((FULL || valid) ? o.gain : 0u);
+    const unsigned long long pending = pending_after_step(done, p.auto_reset);
     uint32_t top = 0;
     if (p.highest)
         top = highest(record_cells(rec));                                                        // :97
@@ -382,7 +458,7 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
         if (!STD && tail.boards_out)
             store_board(tail.boards_out, i, record_cells(rec));
     }
-    flush_episode_counts(counters, episodes, illegal_ends);
+    flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending);
     if constexpr (HAS_OBS)
         emit_onehot<FULL>(s_recs + (threadIdx.x & ~63u), rec, tail.obs, tail.obs_dtype, i_raw & ~63u, n);
     if (!STD && tail.done_seq)
@@ -402,17 +478,19 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
     uint32_t episodes = 0, illegal_ends = 0;
+    unsigned long long gained = 0; // this lane's merge scores over the k steps (reduced over the wave once, at the end)
     for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
                                       p.seed_lo, p.seed_hi);
         const StepOut o = play_record(rec, w.w[3] >> 30, w, p.max_exp, tb);
+        gained += o.gain;
         record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
         if (o.terminated)
             reset_record(rec, o, w, tb);
     }
     if (valid)
         store_board(p.st.boards, i, rec);
-    flush_episode_counts(counters, episodes, illegal_ends);
+    flush_episode_counts(counters, episodes, illegal_ends, wave_sum64_lane63(valid ? gained : 0ull), 0ull);
 }
 
 // ---------------------------------------------------------------- fused rollout with per-step I/O
@@ -473,6 +551,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
     uint32_t episodes = 0, illegal_ends = 0;
+    unsigned long long gained = 0; // this lane's merge scores over the k steps
+    unsigned long long ended_last = 0; // lanes whose episode the LAST step ended (pending marks when auto_reset == 0)
     // step j with its action; t advances with it
     auto one_step = [&](uint32_t j, uint32_t action_in) {
         const size_t o_idx = static_cast<size_t>(j) * stride + i;
@@ -481,7 +561,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
         ++t;
         const uint32_t action = ACT == 0 ? w.w[3] >> 30 : action_in & 3u;
         const StepOut o = play_record(rec, action, w, p.max_exp, tb);
-        record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+        gained += o.gain;
+        ended_last = record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
         if (valid) {
             if (reward)
                 __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, reward + o_idx);
@@ -523,7 +604,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
         one_step(j, static_cast<uint32_t>(fetch(j)));
     if (valid)
         store_board_nt(p.st.boards, i, rec);
-    flush_episode_counts(counters, episodes, illegal_ends);
+    flush_episode_counts(counters, episodes, illegal_ends, wave_sum64_lane63(valid ? gained : 0ull),
+                         pending_after_step(ended_last, p.auto_reset));
 }
 
 // ------------------------------------------------------------------------- numpy-RNG mode
@@ -563,7 +645,9 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     else
         action = load_action<ACT>(p.actions, i, 0u);
 
+    const int32_t score_before = score;
     StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, false);
+    const uint32_t wave_gain = wave_sum_lane63(valid ? static_cast<uint32_t>(score - score_before) : 0u); // :86
 
     const bool fin = r.terminated && valid;
     const Board rec = make_record(bd, static_cast<uint32_t>(score)); // the terminal record where fin
@@ -580,8 +664,8 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
             p.highest[i] = static_cast<uint8_t>(highest(r.terminal));
     }
     uint32_t episodes = 0, illegal_ends = 0;
-    record_episode_ends(p, i, fin, r.illegal, rec, episodes, illegal_ends);
-    flush_episode_counts(counters, episodes, illegal_ends);
+    const unsigned long long ended = record_episode_ends(p, i, fin, r.illegal, rec, episodes, illegal_ends);
+    flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending_after_step(ended, p.auto_reset));
     // ---- hand the finished boards to reset_list_numpy_kernel
     const unsigned long long done = __builtin_amdgcn_ballot_w64(fin && p.auto_reset != 0);
     const uint32_t wave = i_raw >> 6;
@@ -648,10 +732,23 @@ __global__ void __launch_bounds__(kBlock) seed_numpy_kernel(uint64_t *planes, ui
     planes[4ull * n + i] = r.buf;
 }
 
+// Return accounting of an explicit reset (g2048_reset; whole wavefronts): see adjust_slot.
+__device__ __forceinline__ void account_reset(const StepArgs &p, uint32_t i_raw, uint32_t i, bool doit)
+{
+    const bool was_pending = is_pending(p.st.ep_counters, i_raw);
+    int32_t delta = 0;
+    if (doit && !was_pending) // an episode that is still running is abandoned: its score leaves the books
+        delta = -static_cast<int32_t>(record_score(load_board(p.st.boards, i)));
+    adjust_slot(p.st.ep_counters, i_raw, delta, doit);
+}
+
 __global__ void __launch_bounds__(kBlock) reset_numpy_kernel(const StepArgs p, const uint8_t *mask)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= p.n || (mask && mask[i] == 0))
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = i_raw < p.n ? i_raw : p.n - 1u;
+    const bool doit = i_raw < p.n && !(mask && mask[i] == 0);
+    account_reset(p, i_raw, i, doit);
+    if (!doit)
         return;
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
     Board bd{{0u, 0u, 0u, 0u}};   // game2048_env.py:104
@@ -680,10 +777,11 @@ __global__ void __launch_bounds__(kBlock) add_tile_numpy_kernel(const StepArgs p
 // Game2048Env.reset for every (masked) board (game2048_env.py:102-111).
 __global__ void __launch_bounds__(kBlock) reset_kernel(const StepArgs p, uint32_t first_slot, const uint8_t *mask)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= p.n)
-        return;
-    if (mask && mask[i] == 0)
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = i_raw < p.n ? i_raw : p.n - 1u;
+    const bool doit = i_raw < p.n && !(mask && mask[i] == 0);
+    account_reset(p, i_raw, i, doit);
+    if (!doit)
         return;
     const uint32_t b = p.board_offset + i;
     const Words w = philox4x32_10(p.t_lo, p.t_hi, b, first_slot >> 2, p.seed_lo, p.seed_hi);
@@ -793,23 +891,41 @@ __global__ void __launch_bounds__(kBlock) export_scores_kernel(const uint4 *reco
         scores_out[i] = static_cast<int32_t>(record_score(load_board(records, i)));
 }
 
-__global__ void __launch_bounds__(kBlock) import_scores_kernel(uint4 *records, uint32_t n, const int32_t *scores_in)
+__global__ void __launch_bounds__(kBlock) import_scores_kernel(uint4 *records, uint32_t n, const int32_t *scores_in,
+                                                               unsigned long long *ep_counters)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n)
-        return;
-    const Board cells = record_cells(load_board(records, i));
-    store_board(records, i, make_record(cells, static_cast<uint32_t>(scores_in[i]) & kScoreMask));
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < n;
+    const uint32_t i = valid ? i_raw : n - 1u;
+    const Board raw = load_board(records, i);
+    const uint32_t score = static_cast<uint32_t>(scores_in[i]) & kScoreMask;
+    // return accounting: the live score of a running episode changes by (new - old); a board whose episode has ended
+    // keeps its place among the finished ones
+    const bool live = valid && !is_pending(ep_counters, i_raw);
+    adjust_slot(ep_counters, i_raw, live ? static_cast<int32_t>(score) - static_cast<int32_t>(record_score(raw)) : 0, false);
+    if (valid)
+        store_board(records, i, make_record(record_cells(raw), score));
 }
 
-// g2048_seed: forget the finished episodes (game2048_env.py:103 restarts the stream)
-__global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState st, uint32_t n, uint32_t n_counters)
+// g2048_seed: forget the finished episodes (game2048_env.py:103 restarts the stream).  Every slot restarts with
+// G = the scores its 64 boards hold right now (so "G - live scores" = 0: no finished episode) and no pending marks.
+__global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState st, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n)
-        st.last_record[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (i < n_counters)
-        st.ep_counters[i] = 0ull;
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < n;
+    uint32_t score = 0;
+    if (valid) {
+        st.last_record[i_raw] = make_uint4(0u, 0u, 0u, 0u);
+        score = record_score(load_board(st.boards, i_raw));
+    }
+    const uint32_t total = wave_sum_lane63(score); // <= 64 * (2^24 - 1)
+    if ((threadIdx.x & 63u) == 63u) {
+        unsigned long long *slot = st.ep_counters + kSlotWords * (i_raw >> 6);
+        slot[0] = 0ull;
+        slot[1] = 0ull;
+        slot[2] = total;
+        slot[3] = 0ull;
+    }
 }
 
 // final score of each board's most recent finished episode (0 before the first one)
@@ -985,35 +1101,39 @@ __global__ void __launch_bounds__(kBlock) canonicalize_kernel(uint4 *boards, uin
 }
 
 // ----------------------------------------------------------------------------------- stats
-// Reduce to one StatsOut: the episode counters, the returns of the boards' most recent finished
-// episodes (score of last_record: count / sum / max), the highest tile on any board and the histogram
-// of the boards' highest tiles (what ppo_train.py:77-81 tallies per finished episode, here for the
-// live boards).  Two stages and NO global atomics: a single hot cache line serialises at ~88 atomics/us on
-// this chip (a one-stage version spent 55 us at 2^20 boards in its ~5 000 final atomics).
+// Reduce to one StatsOut: the episode counters, the exact sum of the final scores of ALL finished episodes
+// (return_sum = sum of the slots' G - sum of the scores of the boards whose episode is still running, see the slot
+// layout above), the returns of the boards' most recent finished episodes (score of last_record: count / sum / max),
+// the highest tile on any board and the histogram of the boards' highest tiles (what ppo_train.py:77-81 tallies per
+// finished episode, here for the live boards).  Two stages and NO global atomics: a single hot cache line serialises at
+// ~88 atomics/us on this chip (a one-stage version spent 55 us at 2^20 boards in its ~5 000 final atomics).
 //   stage 1: every block reduces its grid-stride share (registers, then a tree in LDS) to kStatsFields
 //            numbers, stored field-major: partials[f * kStatsBlocks + block].  The histogram is counted by
 //            per-wave ballots (the counts are wave-uniform: they live in SGPRs);
 //   stage 2: kStatsFields blocks, block f reduces field f over the partials (coalesced reads, tree in LDS).
 // Cross-lane shuffles are avoided on purpose: a 64-bit __shfl_xor chain costs ~100 cycles per step and the
 // reductions here are latency-, not throughput-bound.
-constexpr int kStatsFields = 6 + 32; // episodes, illegal_ends, last_count, last_score_sum, last_score_max, max_exp, hist[32]
+constexpr int kStatsScalars = 7; // episodes, illegal_ends, last_count, last_score_sum, last_score_max, max_exp, return_sum
+constexpr int kStatsFields = kStatsScalars + 32; // + hist[32]
 static_assert(kStatsFields * kStatsBlocks == kStatsPartialWords, "partials buffer size");
 
-// WITH_BOARDS = false is the RETURNS-ONLY flavour (what a multi-GPU job all-gathers once per rollout): counters and
-// terminal records only -- the live boards are not read (half the traffic) and the 32 ballots per 64 boards of the
-// histogram are not executed; max_exp and highest_hist[] come out as zero.
-template <bool WITH_BOARDS>
+// FULL_STATS = false is the RETURNS-ONLY flavour (what a multi-GPU job all-gathers once per rollout): the slots and the
+// live records only -- episodes, illegal_ends and the exact return_sum.  The terminal records are not read (half the
+// traffic) and the 32 ballots per 64 boards of the histogram are not executed; last_*, max_exp and highest_hist[] come
+// out as zero.
+template <bool FULL_STATS>
 __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
                                                        unsigned long long *partials)
 {
-    __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock], s_cnt[kBlock];
+    __shared__ unsigned long long s_ep[kBlock], s_ill[kBlock], s_sum[kBlock], s_cnt[kBlock], s_ret[kBlock];
     __shared__ unsigned int s_max[kBlock], s_exp[kBlock];
     __shared__ unsigned int s_hist[32];
     unsigned long long episodes = 0, illegal = 0, score_sum = 0, count = 0;
+    unsigned long long ret = 0; // sum of G over this thread's slots - sum of the live scores of its boards (mod 2^64)
     unsigned int max_score = 0, max_exp = 0;
-    uint32_t hist[WITH_BOARDS ? 32 : 1];
+    uint32_t hist[FULL_STATS ? 32 : 1];
 #pragma unroll
-    for (int b = 0; b < (WITH_BOARDS ? 32 : 1); ++b)
+    for (int b = 0; b < (FULL_STATS ? 32 : 1); ++b)
         hist[b] = 0u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < 32u)
@@ -1021,36 +1141,42 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
     __syncthreads();
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t wv = blockIdx.x * kBlock + tid; wv < n_waves; wv += stride) {
-        const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(st.ep_counters + 2u * wv);
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(st.ep_counters + kSlotWords * wv);
         episodes += c.x;
         illegal += c.y;
+        ret += st.ep_counters[kSlotWords * wv + 2u];
     }
     // whole wavefronts iterate together (the ballots need every lane's vote): lanes past the end vote "none"
     for (uint64_t base = blockIdx.x * kBlock + tid - lane; base < n; base += stride) { // 64-bit: n may be near 2^32
         const uint64_t i = base + lane;
+        // boards whose episode has ended but which were not reset (auto_reset == 0): their score is a finished episode's
+        const unsigned long long pending = st.ep_counters[kSlotWords * (base >> 6) + 3u]; // uniform address: scalar load
         uint32_t h = 0xffu;
         if (i < n) {
-            const Board last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
-            if constexpr (WITH_BOARDS) {
-                h = highest(record_cells(load_board_nt(st.boards, static_cast<uint32_t>(i))));
+            const Board live = load_board_nt(st.boards, static_cast<uint32_t>(i));
+            if (((pending >> lane) & 1ull) == 0ull)
+                ret -= record_score(live);
+            if constexpr (FULL_STATS) {
+                h = highest(record_cells(live));
                 max_exp = max(max_exp, h);
-            }
-            if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
-                const unsigned int sc = record_score(last);
-                count += 1;
-                score_sum += sc;
-                max_score = max(max_score, sc);
+                const Board last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
+                if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
+                    const unsigned int sc = record_score(last);
+                    count += 1;
+                    score_sum += sc;
+                    max_score = max(max_score, sc);
+                }
             }
         }
-        if constexpr (WITH_BOARDS) {
+        if constexpr (FULL_STATS) {
 #pragma unroll
             for (uint32_t b = 0; b < 32u; ++b)
                 hist[b] += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(h == b)));
         }
     }
-    s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_cnt[tid] = count;
+    s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_cnt[tid] = count; s_ret[tid] = ret;
     s_max[tid] = max_score; s_exp[tid] = max_exp;
-    if constexpr (WITH_BOARDS) {
+    if constexpr (FULL_STATS) {
         if (lane == 0u) {
 #pragma unroll
             for (int b = 0; b < 32; ++b)
@@ -1065,6 +1191,7 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
             s_ill[tid] += s_ill[tid + off];
             s_sum[tid] += s_sum[tid + off];
             s_cnt[tid] += s_cnt[tid + off];
+            s_ret[tid] += s_ret[tid + off];
             s_max[tid] = max(s_max[tid], s_max[tid + off]);
             s_exp[tid] = max(s_exp[tid], s_exp[tid + off]);
         }
@@ -1078,25 +1205,21 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
         mine[3 * kStatsBlocks] = s_sum[0];
         mine[4 * kStatsBlocks] = s_max[0];
         mine[5 * kStatsBlocks] = s_exp[0];
+        mine[6 * kStatsBlocks] = s_ret[0];
     }
-    if (WITH_BOARDS && tid < 32u)
-        mine[(6u + tid) * kStatsBlocks] = s_hist[tid];
+    if (FULL_STATS && tid < 32u)
+        mine[(kStatsScalars + tid) * kStatsBlocks] = s_hist[tid];
 }
 
-// block f: field f of every partial -> the matching member of *out (fields 4 and 5 are maxima, the rest sums)
-// (the returns-only flavour launches the first six blocks only; block 5 then clears max_exp and the histogram)
+// block f: field f of every partial -> the matching member of *out (fields 4 and 5 are maxima, the rest sums mod 2^64)
+// (the returns-only flavour launches the first kStatsScalars blocks only; block 5 then also clears the histogram)
 __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long long *partials, uint32_t n_partials,
                                                              StatsOut *out)
 {
     __shared__ unsigned long long s_v[kBlock];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    if (gridDim.x == 6u && f == 5u) { // returns-only: nothing was counted for these
-        if (tid < 32u)
-            out->highest_hist[tid] = 0u;
-        if (tid == 0)
-            out->max_exp = 0u;
-        return;
-    }
+    if (gridDim.x == static_cast<uint32_t>(kStatsScalars) && f == 5u && tid < 32u) // returns-only: nothing was counted for these
+        out->highest_hist[tid] = 0u;
     const bool is_max = f == 4u || f == 5u;
     unsigned long long v = 0;
     for (uint32_t q = tid; q < n_partials; q += kBlock) {
@@ -1122,7 +1245,8 @@ __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long
     case 3: out->last_score_sum = v; break;
     case 4: out->last_score_max = static_cast<int>(v); break;
     case 5: out->max_exp = static_cast<unsigned int>(v); break;
-    default: out->highest_hist[f - 6u] = static_cast<unsigned int>(v); break;
+    case 6: out->return_sum = static_cast<long long>(v); break;
+    default: out->highest_hist[f - kStatsScalars] = static_cast<unsigned int>(v); break;
     }
 }
 
@@ -1357,7 +1481,7 @@ hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *p
         blocks = 1; // n == 0: one block writes an all-zero partial
     if (returns_only) {
         hipLaunchKernelGGL(stats_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
-        hipLaunchKernelGGL(stats_merge_kernel, dim3(6), dim3(kBlock), 0, s, partials, blocks, dev_out);
+        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsScalars), dim3(kBlock), 0, s, partials, blocks, dev_out);
     } else {
         hipLaunchKernelGGL(stats_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
         hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out);
@@ -1389,11 +1513,12 @@ hipError_t launch_export_scores(const uint4 *records, uint32_t n, int32_t *score
     return hipGetLastError();
 }
 
-hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, hipStream_t s)
+hipError_t launch_import_scores(uint4 *records, uint32_t n, const int32_t *scores_in, unsigned long long *ep_counters,
+                                hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(import_scores_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, scores_in);
+    hipLaunchKernelGGL(import_scores_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, scores_in, ep_counters);
     return hipGetLastError();
 }
 
@@ -1401,7 +1526,7 @@ hipError_t launch_clear_stats(const DeviceState &st, uint32_t n, hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(clear_stats_kernel, grid_for(n), dim3(kBlock), 0, s, st, n, 2u * ((n + 63u) / 64u));
+    hipLaunchKernelGGL(clear_stats_kernel, grid_for(n), dim3(kBlock), 0, s, st, n);
     return hipGetLastError();
 }
 

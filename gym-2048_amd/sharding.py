@@ -75,7 +75,7 @@ def allgather_returns(local_returns: torch.Tensor, shard: Shard) -> torch.Tensor
 
 def allgather_stats(local_stats: torch.Tensor) -> torch.Tensor:
     """All-gather the per-rank episodic-return SUMMARY (``Batched2048.episode_stats_device()``: the C struct
-    g2048_stats as ``uint8 [168]``) -> ``uint8 [world, 168]`` on every rank.  A few hundred bytes per rank:
+    g2048_stats as ``uint8 [sizeof]``) -> ``uint8 [world, sizeof]`` on every rank.  176 bytes per rank:
     one latency-bound RCCL all-gather per rollout (SURVEY 8e's first option)."""
     if not dist.is_initialized():
         return local_stats.reshape(1, -1).clone()
@@ -92,8 +92,10 @@ def merge_stats(rows) -> dict:
     tot = dict(episodes=sum(p["episodes"] for p in parts), illegal_ends=sum(p["illegal_ends"] for p in parts),
                last_count=sum(p["last_count"] for p in parts), last_score_sum=sum(p["last_score_sum"] for p in parts),
                last_score_max=max(p["last_score_max"] for p in parts), max_exp=max(p["max_exp"] for p in parts),
-               highest_hist=[sum(col) for col in zip(*(p["highest_hist"] for p in parts))])
+               highest_hist=[sum(col) for col in zip(*(p["highest_hist"] for p in parts))],
+               return_sum=sum(p["return_sum"] for p in parts))
     tot["mean_last_score"] = tot["last_score_sum"] / tot["last_count"] if tot["last_count"] else 0.0
+    tot["mean_episode_score"] = tot["return_sum"] / tot["episodes"] if tot["episodes"] else 0.0
     return tot
 
 

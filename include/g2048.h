@@ -28,7 +28,7 @@
  *    (cells = byte & 0x1f).  Scores are exact in 0 .. 2^24 - 1.
  *  - An engine is not thread-safe; use one engine per device per process.  All calls on one engine must also be
  *    STREAM-ORDERED: issue them on one stream, or order the streams with events.  The episode counters are
- *    updated without atomics (one wavefront per counter pair per launch), the statistics reduction has one
+ *    updated without atomics (one wavefront per counter slot per launch), the statistics reduction has one
  *    scratch area per engine, and the get / set calls with host buffers share one staging buffer -- two calls in flight
  *    on different streams can corrupt each other's results.  (The all-gather has its own send buffer.)
  *  - Value ranges: cell exponents 0..30 (set_boards takes them mod 32; a merge of two 2^31 tiles would overflow the
@@ -120,6 +120,17 @@ typedef struct {
     uint32_t max_exp;        /* highest exponent currently on any board */
     uint32_t highest_hist[32]; /* highest_hist[k] = boards whose highest tile (game2048_env.py:190-192) is 2^k
                                 * right now (k = 0: empty board) -- what ppo_train.py:77-81 tallies */
+    int64_t return_sum;      /* EXACT sum of the final merge scores (game2048_env.py:86) of ALL `episodes` finished
+                              * episodes -- what SB3's Monitor averages as info["episode"]["r"] (ppo_train.py:123), minus
+                              * the illegal-move rewards: mean episodic return = (return_sum + illegal_ends *
+                              * illegal_move_reward) / episodes.  Kept by conservation, with no per-episode work in the
+                              * step: every wavefront adds the merge scores of its 64 moves to a running total G, and
+                              * return_sum = sum of G - sum of the scores of the episodes still running.  An episode
+                              * counts from the step that ends it (with auto_reset == 0: although its score is still in
+                              * the record); an episode ABANDONED by g2048_reset before it ended is in neither `episodes`
+                              * nor return_sum; g2048_set_scores moves a running episode's score without touching the
+                              * finished ones.  (Stepping a board again after its episode has ended, without a reset,
+                              * continues that episode: it is counted once more when it ends again, its score once.) */
 } g2048_stats;
 
 typedef struct g2048_comm g2048_comm;
@@ -256,9 +267,9 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
  * synchronisation: the per-rank episodic-return summary a multi-GPU job all-gathers. */
 int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, void *stream);
 /* The RETURNS-ONLY form of the same call -- what the once-per-rollout exchange of a multi-GPU job needs and nothing
- * else: episodes, illegal_ends, last_count, last_score_sum, last_score_max from the counters and the terminal
- * records; the live boards are not read, max_exp and highest_hist[] are written as zero.  Half the traffic and a
- * third of the time of the full reduction. */
+ * else: episodes, illegal_ends and the exact return_sum, from the episode slots and the live records.  The terminal
+ * records are not read and the histogram is not counted: last_count, last_score_sum, last_score_max, max_exp and
+ * highest_hist[] are written as zero.  Half the traffic and two thirds of the time of the full reduction. */
 int g2048_returns_summary_async(const g2048_engine *e, g2048_stats *device_out, void *stream);
 
 /* numpy-compatible RNG mode: every board draws from its OWN numpy PCG64 exactly as the reference does

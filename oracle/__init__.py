@@ -104,6 +104,47 @@ class OracleBatch:
         self.last_score = np.zeros(n, np.int32)
         self.last_len = np.zeros(n, np.int32)
         self.ep_count = np.zeros(n, np.uint32)
+        # ---- return accounting: the checker's side of g2048_stats.return_sum, kept two independent ways
+        # (a) finished_return_sum: the final score of every episode, added at the step that ends it (what SB3's Monitor
+        #     sums as info["episode"]["r"], ppo_train.py:123, minus illegal-move rewards)
+        # (b) the conservation form the device uses: every merge score ever made is either on a live board or belongs to
+        #     a finished episode -> return_sum = gain_total - sum(score of boards whose episode is still running);
+        #     `pending` = episode ended but the board was not reset (auto_reset off): no longer "running"
+        # With auto_reset always on the two agree; (b) also defines the edge cases (masked resets abandon running
+        # episodes, a board stepped again after its episode ended continues that episode).
+        self.finished_return_sum = 0
+        self.gain_total = 0
+        self.pending = np.zeros(n, bool)
+
+    @property
+    def return_sum(self) -> int:
+        return self.gain_total - int(self.score[~self.pending].astype(np.int64).sum())
+
+    def _clear_return_accounting(self):
+        """g2048_seed: the statistics restart; scores already on the boards are not gains of the new books."""
+        self.pending[:] = False
+        self.gain_total = int(self.score.astype(np.int64).sum())
+        self.finished_return_sum = 0
+
+    def _account_reset(self, sel):
+        """Boards ``sel`` are about to be reset: a running episode is abandoned (its score leaves the books), an ended
+        one keeps its place among the finished."""
+        self.gain_total -= int(self.score[sel & ~self.pending].astype(np.int64).sum())
+        self.pending[sel] = False
+
+    def _account_step(self, auto_reset: bool):
+        done = self.terminated.astype(bool)
+        legal = self.illegal == 0
+        self.gain_total += int(self.reward[legal].astype(np.int64).sum())          # :86 (an illegal move scores nothing)
+        self.finished_return_sum += int(self.last_score[done].astype(np.int64).sum())
+        self.pending[:] = False if auto_reset else done      # every board was stepped: older marks are gone
+
+    def set_scores(self, scores):
+        """g2048_set_scores: the score of a running episode moves; a board whose episode has ended keeps its place."""
+        scores = np.asarray(scores, dtype=np.int32)
+        live = ~self.pending
+        self.gain_total += int(scores[live].astype(np.int64).sum()) - int(self.score[live].astype(np.int64).sum())
+        self.score[:] = scores
 
     def _batch(self, actions=None):
         return _Batch(_ptr(self.boards), _ptr(self.score), _ptr(self.ep_start), _ptr(actions),
@@ -113,16 +154,23 @@ class OracleBatch:
 
     def seed_(self, seed: int):
         self.seed, self.t, self.fresh = seed, 0, True
+        self._clear_return_accounting()
 
-    def reset(self, first_slot: int = 0, new_transaction=None):
+    def reset(self, first_slot: int = 0, new_transaction=None, mask=None):
+        """``mask``: uint8[n], only boards with mask != 0 are reset (g2048_reset's mask)."""
         if new_transaction is None:
             new_transaction = not self.fresh
         if new_transaction:
             self.t += 1
         self.fresh = False
+        sel = np.ones(self.n, bool) if mask is None else np.asarray(mask) != 0
+        self._account_reset(sel)
+        keep = (self.boards.copy(), self.score.copy(), self.ep_start.copy()) if mask is not None else None
         b = self._batch()
         self.lib.g2048o_reset_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset, first_slot,
                                     self.threads)
+        if keep is not None:
+            self.boards[~sel], self.score[~sel], self.ep_start[~sel] = keep[0][~sel], keep[1][~sel], keep[2][~sel]
 
     def step(self, actions=None, auto_reset: bool = True):
         """actions: uint8[n] or None for the synthetic random policy."""
@@ -134,6 +182,7 @@ class OracleBatch:
         b = self._batch(actions)
         self.lib.g2048o_step_batch(C.byref(b), self.n, self.seed, self.t, self.board_offset,
                                    self.illegal_move_reward, self.max_exp, int(auto_reset), self.threads)
+        self._account_step(auto_reset)
 
     # -- numpy-compatible RNG mode: rng[i] = (state_lo, state_hi, inc_lo, inc_hi, buf) of board i
     def seed_numpy(self, seed: int):
@@ -141,10 +190,12 @@ class OracleBatch:
         env i of a vector env seeded with ``seed`` (SB3 seeds env i with seed + i)."""
         self.rng = pcg64_states_from_seeds(seed + self.board_offset + np.arange(self.n))
         self.seed, self.t, self.fresh = seed, 0, True
+        self._clear_return_accounting()
 
     def reset_numpy(self):
         b = self._batch()
         self.fresh = False
+        self._account_reset(np.ones(self.n, bool))
         self.lib.g2048o_reset_batch_numpy(C.byref(b), self.rng.ctypes.data, self.n, self.t, self.threads)
 
     def step_numpy(self, actions=None, auto_reset: bool = True):
@@ -155,6 +206,7 @@ class OracleBatch:
         self.lib.g2048o_step_batch_numpy(C.byref(b), self.rng.ctypes.data, self.n, self.seed, self.t,
                                          self.board_offset, self.illegal_move_reward, self.max_exp,
                                          int(auto_reset), self.threads)
+        self._account_step(auto_reset)
 
     def onehot(self):
         out = np.zeros((self.n, 16, 4, 4), np.uint8)

@@ -66,6 +66,7 @@ int main(int argc, char **argv)
     b.last_score = o_last.data(); b.last_len = o_len.data(); b.ep_count = o_count.data();
     g2048o_reset_batch(&b, n, seed, 0, offset, 0, 0);
     uint64_t episodes = 0, illegal_ends = 0;
+    int64_t return_sum = 0; // final score of every finished episode, added when it ends (the oracle writes last_score then)
     for (uint32_t j = 0; j < steps; ++j) {
         b.actions = actions.data() + static_cast<size_t>(j) * n;
         g2048o_step_batch(&b, n, seed, 1 + j, offset, -1.0f, 0, 1, 0);
@@ -80,6 +81,8 @@ int main(int argc, char **argv)
             }
             episodes += o_term[i];
             illegal_ends += o_term[i] && o_ill[i];
+            if (o_term[i])
+                return_sum += o_last[i];
         }
     }
     if (std::memcmp(boards.data(), o_boards.data(), n * 16) || std::memcmp(scores.data(), o_score.data(), n * 4) ||
@@ -90,6 +93,10 @@ int main(int argc, char **argv)
     if (st.episodes != episodes || st.illegal_ends != illegal_ends) {
         std::printf("FAIL episode counters %llu/%llu vs %llu/%llu\n", (unsigned long long)st.episodes,
                     (unsigned long long)st.illegal_ends, (unsigned long long)episodes, (unsigned long long)illegal_ends);
+        return 1;
+    }
+    if (st.return_sum != return_sum) {
+        std::printf("FAIL return_sum %lld vs the oracle's %lld\n", (long long)st.return_sum, (long long)return_sum);
         return 1;
     }
     // ---- phase 2: the step that returns its observation (g2048_step_io.obs, one launch) and the host-resident step

@@ -28,7 +28,8 @@ def main():
     summ = merge_stats(allgather_stats(eng.episode_stats_device().cpu()))    # per-rank summary structs
     if rank == 0:
         np.savez(out, returns=returns.numpy(), boards=torch.cat(boards).numpy(), episodes=summ["episodes"],
-                 last_sum=summ["last_score_sum"], last_max=summ["last_score_max"], hist=np.array(summ["highest_hist"]))
+                 last_sum=summ["last_score_sum"], last_max=summ["last_score_max"], hist=np.array(summ["highest_hist"]),
+                 return_sum=summ["return_sum"])
     dist.barrier()
     dist.destroy_process_group()
 

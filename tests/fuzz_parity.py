@@ -8,7 +8,8 @@ reward, max_tile, auto_reset; then 12-40 calls chosen among
   fused rollout of k steps (pipelined action loads: every tail length occurs)
   rollout_random(k)
   step_host (host-resident I/O)
-  masked reset, set_boards round trip, state save / restore into a second engine
+  masked reset, set_boards, set_scores, state save / restore into a second engine
+and after every call the boards, scores, last returns, episode counts and the exact return sum (both statistics flavours)
     python tests/fuzz_parity.py [seconds=120] [seed=0]"""
 import ctypes as C
 import sys
@@ -22,7 +23,7 @@ import __graft_entry__ as ge
 
 ge.build()
 from gym2048_amd import _lib
-from gym2048_amd.batched import Batched2048
+from gym2048_amd.batched import Batched2048, parse_stats
 from oracle import OracleBatch
 
 rs = np.random.default_rng(0)
@@ -35,13 +36,18 @@ def bump(name):
     counts[name] = counts.get(name, 0) + 1
 
 
-def check_state(eng, ora, where):
+def check_state(eng, ora, where, always_auto_reset=False):
     n = eng.n_envs
     assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards), where
     assert np.array_equal(eng.get_scores(), ora.score), where
     assert np.array_equal(eng.get_last_scores(), ora.last_score), where
     st = eng.episode_stats()
     assert st["episodes"] == int(ora.ep_count.sum()), where
+    assert st["return_sum"] == ora.return_sum, (where, st["return_sum"], ora.return_sum, ora.finished_return_sum)
+    if always_auto_reset:                       # then it IS the sum of the final scores of all finished episodes
+        assert st["return_sum"] == ora.finished_return_sum, where
+    ro = parse_stats(eng.episode_stats_device(returns_only=True))
+    assert (ro["episodes"], ro["illegal_ends"], ro["return_sum"]) == (st["episodes"], st["illegal_ends"], st["return_sum"]), where
 
 
 def one_case(case):
@@ -69,8 +75,8 @@ def one_case(case):
     bump("numpy_mode_cases" if numpy_mode else "philox_cases")
     tag = f"case {case}: n={n} seed={seed} offset={offset} irw={irw} max_tile={max_tile} auto_reset={auto_reset} numpy={numpy_mode}"
     for call in range(int(rs.integers(12, 40))):
-        kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state"],
-                             p=[0.3, 0.18, 0.15, 0.08, 0.12, 0.06, 0.05, 0.06]))
+        kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state", "set_scores"],
+                             p=[0.3, 0.18, 0.15, 0.08, 0.1, 0.06, 0.04, 0.06, 0.03]))
         if numpy_mode and kind in ("fused", "random", "mask_reset"):   # spawn-stream-only calls / unmaskable oracle reset
             kind = "step"
         where = f"{tag} call {call} {kind}"
@@ -140,15 +146,15 @@ def one_case(case):
         elif kind == "mask_reset":
             mask = (rs.random(n) < 0.3).astype(np.uint8)
             eng.reset(mask=mask)
-            keep = ora.boards.copy(), ora.score.copy()
-            ora.reset()
-            sel = mask == 0
-            ora.boards[sel] = keep[0][sel]
-            ora.score[sel] = keep[1][sel]
+            ora.reset(mask=mask)
         elif kind == "set_boards":
             b = (rs.integers(0, 12, (n, 16)) * (rs.random((n, 16)) < 0.6)).astype(np.uint8)
             eng.set_boards(b)
             ora.boards[:] = b
+        elif kind == "set_scores":
+            sc = rs.integers(0, 1 << 20, n).astype(np.int32)
+            eng.set_scores(sc if rs.random() < 0.5 else torch.as_tensor(sc).to(dev))
+            ora.set_scores(sc)
         else:  # state save / restore into a fresh engine that then replaces the original
             blob = eng.state_dict()
             other = Batched2048(n, seed=1, board_offset=0, rng="numpy" if numpy_mode else "philox")
@@ -157,7 +163,7 @@ def one_case(case):
             eng = other
             eng.set_illegal_move_reward(irw)
             eng.set_max_tile(max_tile)
-        check_state(eng, ora, where)
+        check_state(eng, ora, where, always_auto_reset=auto_reset)
     eng.close()
 
 

@@ -45,7 +45,7 @@ def test_struct_layouts():
     from gym2048_amd import _lib
     assert C.sizeof(_lib.StepIO) == 80      # 10 x 8 bytes (the two int32 dtype codes padded)
     assert C.sizeof(_lib.HostIO) == 64
-    assert C.sizeof(_lib.Stats) == 168     # 40 + uint32 highest_hist[32]
+    assert C.sizeof(_lib.Stats) == 176     # 40 + uint32 highest_hist[32] + int64 return_sum
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -39,7 +39,7 @@ def _worker(rank, world, port, n_global, steps, seed, out_dir):
         had = ob.ep_count > 0
         st = Stats(episodes=int(ob.ep_count.sum()), illegal_ends=0, last_count=int(had.sum()),
                    last_score_sum=int(ob.last_score[had].sum()), last_score_max=int(ob.last_score.max()),
-                   max_exp=int(ob.boards.max()))
+                   max_exp=int(ob.boards.max()), return_sum=ob.return_sum)
         for k, v in enumerate(np.bincount(ob.boards.max(axis=1), minlength=32)):
             st.highest_hist[k] = int(v)
         rows = allgather_stats(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
@@ -56,7 +56,7 @@ def _worker(rank, world, port, n_global, steps, seed, out_dir):
         if rank == 0:
             np.savez(os.path.join(out_dir, "gathered.npz"), returns=returns.numpy(), boards=boards.numpy(),
                      episodes=summ["episodes"], max_score=summ["last_score_max"], last_count=summ["last_count"],
-                     last_sum=summ["last_score_sum"], hist=np.array(summ["highest_hist"]))
+                     last_sum=summ["last_score_sum"], hist=np.array(summ["highest_hist"]), return_sum=summ["return_sum"])
     finally:
         dist.destroy_process_group()
 
@@ -76,6 +76,7 @@ def test_sharded_ranks_equal_single_process(tmp_path, n_global, world):
     assert int(got["episodes"]) == int(ref.ep_count.sum()) and int(got["max_score"]) == int(ref.last_score.max())
     assert int(got["last_count"]) == int((ref.ep_count > 0).sum()) and int(got["last_sum"]) == int(ref.last_score.sum())
     assert np.array_equal(got["hist"], np.bincount(ref.boards.max(axis=1), minlength=32))
+    assert int(got["return_sum"]) == ref.return_sum == ref.finished_return_sum > 0      # the exact all-episode return sum
 
 
 def test_allgather_single_process_is_identity():

@@ -113,6 +113,109 @@ def test_set_scores_set_clock_round_trips(torch_cuda):
     assert eng.clock == (1 << 33) + 12
 
 
+@pytest.mark.parametrize("rng", ["philox", "numpy"])
+def test_return_sum_accounting_through_every_call_that_moves_a_score(torch_cuda, rng):
+    """g2048_stats.return_sum -- the exact sum of the final scores of ALL finished episodes -- is kept by conservation
+    (sum of every wavefront's running gain total minus the scores of the episodes still running), so every call that
+    moves a score has to keep the books: steps with and without auto-reset (an ended, un-reset episode is finished
+    although its score is still in the record), per-step / [k,n] / fused / random rollouts, full and masked resets
+    (a running episode is abandoned), set_scores, set_boards, reseeding (books restart at zero), state round trips.
+    After every call: both statistics flavours == the oracle's books; with auto-reset only, == the plain sum of the
+    final scores the oracle saw episode by episode."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048, parse_stats
+    from oracle import OracleBatch
+    n, seed = 5000, 77
+    numpy_mode = rng == "numpy"
+    eng, ora = Batched2048(n, seed=seed, illegal_move_reward=-1.0, rng=rng), OracleBatch(n, seed)
+    ora.illegal_move_reward = -1.0
+    if numpy_mode:
+        ora.seed_numpy(seed)
+        ora.step, ora.reset = ora.step_numpy, (lambda mask=None: ora.reset_numpy())
+    rs = np.random.default_rng(5)
+
+    def check(where, plain_sum=False):
+        st = eng.episode_stats()
+        assert st["episodes"] == int(ora.ep_count.sum()), where
+        assert st["return_sum"] == ora.return_sum, (where, st["return_sum"], ora.return_sum)
+        if plain_sum:
+            assert st["return_sum"] == ora.finished_return_sum, where
+        ro = parse_stats(eng.episode_stats_device(returns_only=True))
+        assert (ro["episodes"], ro["illegal_ends"], ro["return_sum"]) == (st["episodes"], st["illegal_ends"], st["return_sum"]), where
+        assert np.array_equal(eng.get_scores(), ora.score), where
+
+    eng.reset()
+    ora.reset()
+    check("reset")
+    for s in range(40):                                          # auto-reset: the plain per-episode sum
+        a = rs.integers(0, 4, n).astype(np.uint8)
+        eng.step(a)
+        ora.step(a)
+        if s % 8 == 7:
+            check(f"auto-reset step {s}", plain_sum=True)
+    assert ora.finished_return_sum > 0
+    for s in range(30):                                          # no auto-reset: ended episodes stay on the board (pending)
+        a = rs.integers(0, 4, n).astype(np.uint8)
+        eng.step(a, auto_reset=False)
+        ora.step(a, auto_reset=False)
+        if s % 6 == 5:
+            check(f"no-reset step {s}")
+    assert ora.pending.any()
+    if not numpy_mode:
+        mask = (rs.random(n) < 0.4).astype(np.uint8)             # resets some pending, some running (abandoned) boards
+        eng.reset(mask=mask)
+        ora.reset(mask=mask)
+        check("masked reset")
+    sc = rs.integers(0, 1 << 22, n).astype(np.int32)
+    eng.set_scores(sc)
+    ora.set_scores(sc)
+    check("set_scores (host)")
+    sc = rs.integers(0, 1 << 22, n).astype(np.int32)
+    eng.set_scores(torch.as_tensor(sc).to(eng.device))
+    ora.set_scores(sc)
+    check("set_scores (device)")
+    b = (rs.integers(0, 12, (n, 16)) * (rs.random((n, 16)) < 0.6)).astype(np.uint8)
+    eng.set_boards(b)
+    ora.boards[:] = b
+    check("set_boards")
+    k = 9
+    acts = torch.as_tensor(rs.integers(0, 4, (k, n)).astype(np.uint8)).to(eng.device)
+    for fused, auto in ((False, False), (True, False), (True, True), (False, True)):
+        if fused and numpy_mode:
+            continue
+        eng.rollout(acts, auto_reset=auto, fused=fused)
+        for j in range(k):
+            ora.step(acts[j].cpu().numpy(), auto_reset=auto)
+        check(f"rollout fused={fused} auto_reset={auto}")
+    if not numpy_mode:
+        eng.rollout_random(37)
+        for _ in range(37):
+            ora.step(None)
+        check("rollout_random")
+    eng.reset()                                                  # full reset: pending marks cleared, running episodes abandoned
+    ora.reset()
+    check("full reset")
+    blob = eng.state_dict()
+    other = Batched2048(n, seed=1, rng=rng)
+    other.load_state_dict(blob)
+    other.set_illegal_move_reward(-1.0)
+    eng.close()
+    eng = other
+    check("state round trip")
+    eng.seed(seed + 1)                                           # the books restart: nothing finished, live scores carried
+    ora.seed_numpy(seed + 1) if numpy_mode else ora.seed_(seed + 1)
+    ora.ep_count[:] = 0
+    check("reseed")
+    assert eng.episode_stats()["return_sum"] == 0
+    for s in range(12):
+        a = rs.integers(0, 4, n).astype(np.uint8)
+        eng.step(a)
+        ora.step(a)
+    check("after reseed")
+    st = eng.episode_stats()
+    assert st["mean_episode_return"] == (st["return_sum"] - st["illegal_ends"]) / st["episodes"]     # illegal_move_reward = -1
+
+
 def test_rollout_writes_terminal_boards(torch_cuda):
     """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
     episode and holds the board the episode ended on."""
@@ -172,7 +275,7 @@ def test_canonicalize_vs_reference_table_and_oracle(torch_cuda):
     host = np.zeros((64, 16), np.uint8)
     host_actions = np.zeros(64, np.uint8)
     assert lib.g2048_canonicalize(host.ctypes.data, None, None, 64, None, None) == -1
-    assert b"not device memory" in lib.g2048_last_error()
+    assert b"pageable host memory" in lib.g2048_last_error()
     out = np.zeros((8 * 64, 16), np.uint8)
     assert lib.g2048_augment(host.ctypes.data, None, host_actions.ctypes.data, 64, out.ctypes.data, None,
                              np.zeros(8 * 64, np.uint8).ctypes.data, None) == -1

@@ -170,10 +170,11 @@ def test_two_rank_hip_shards_allgather(torch_cuda, tmp_path):
     assert int(got["last_max"]) == st["last_score_max"] and got["hist"].tolist() == st["highest_hist"]
     from gym2048_amd.batched import parse_stats
     assert parse_stats(whole.episode_stats_device()) == st                  # async device struct == sync host struct
-    ro = parse_stats(whole.episode_stats_device(returns_only=True))         # returns-only flavour: same returns, no boards
-    for key in ("episodes", "illegal_ends", "last_count", "last_score_sum", "last_score_max", "mean_last_score"):
+    ro = parse_stats(whole.episode_stats_device(returns_only=True))         # returns-only flavour: counts + exact return sum
+    for key in ("episodes", "illegal_ends", "return_sum", "mean_episode_score"):
         assert ro[key] == st[key], key
-    assert ro["max_exp"] == 0 and not any(ro["highest_hist"])
+    assert ro["max_exp"] == 0 and not any(ro["highest_hist"]) and ro["last_count"] == ro["last_score_sum"] == 0
+    assert int(got["return_sum"]) == st["return_sum"] > 0                   # the two shards' summaries add up to the whole
 
 
 @pytest.mark.parametrize("gather", ["summary", "full"])
@@ -205,7 +206,8 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
     assert t["collective_us"] < t["launch_train_us"], t
     if gather == "summary":
         assert line["global_returns"]["episodes"] == line["episodes_finished"]
-        assert line["global_returns"]["mean_last_episode_score"] == line["mean_last_episode_score"]
+        assert line["global_returns"]["return_sum"] == line["return_sum"] > 0
+        assert line["global_returns"]["mean_episode_score"] == line["mean_episode_score"]
 
 
 @pytest.mark.parametrize("gather", ["summary", "full"])

@@ -161,6 +161,11 @@ def test_random_rollout_vs_oracle(torch_cuda, n, seed, offset, irw, max_tile, au
     st = g.eng.episode_stats()
     had = o.ep_count > 0                                    # boards that finished at least one episode
     assert st["episodes"] == int(o.ep_count.sum()) and st["illegal_ends"] == illegal_ends
+    # the exact return sum: by the device's conservation form, and -- with auto-reset -- as the sum of the final scores of
+    # ALL finished episodes (SB3 Monitor's episode returns, ppo_train.py:123), which the oracle adds up episode by episode
+    assert st["return_sum"] == o.return_sum
+    if auto_reset:
+        assert st["return_sum"] == o.finished_return_sum and st["mean_episode_score"] == o.finished_return_sum / max(1, st["episodes"])
     assert st["last_count"] == int(had.sum()) and st["last_score_sum"] == int(o.last_score[had].sum())
     assert st["last_score_max"] == (int(o.last_score[had].max()) if had.any() else 0)
     assert st["max_exp"] == int(o.boards.max())
@@ -550,6 +555,7 @@ def test_full_size_conservation_over_a_rollout(torch_cuda):
         last = torch.where(done, run, last)
         run[done] = 0
     assert int(rew.sum(dtype=torch.float64)) == int(finished) + int(a.scores().sum(dtype=torch.int64))
+    assert st["return_sum"] == int(finished)                           # g2048_stats.return_sum: ALL finished episodes, exact
     assert torch.equal(a.last_scores().to(torch.float64), last)       # the returns the all-gather ships
     assert st["last_score_sum"] == int(last.sum()) and st["last_score_max"] == int(last.max())
     assert 0 < st["illegal_ends"] <= st["episodes"] and st["last_score_max"] >= st["mean_last_score"] > 0

@@ -127,8 +127,8 @@ int main(int argc, char **argv)
     StepArgs a{};
     uint4 *b16;
     CHECK(hipMalloc(&a.st.boards, (size_t)n * 16)); CHECK(hipMalloc(&b16, (size_t)n * 16));
-    CHECK(hipMalloc(&a.st.last_record, (size_t)n * 16)); CHECK(hipMalloc(&a.st.ep_counters, (size_t)(n / 64 + 16) * 16));
-    CHECK(hipMemset(a.st.last_record, 0, (size_t)n * 16)); CHECK(hipMemset(a.st.ep_counters, 0, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMalloc(&a.st.last_record, (size_t)n * 16)); CHECK(hipMalloc(&a.st.ep_counters, (size_t)(n / 64 + 16) * 32));
+    CHECK(hipMemset(a.st.last_record, 0, (size_t)n * 16)); CHECK(hipMemset(a.st.ep_counters, 0, (size_t)(n / 64 + 16) * 32));
     uint8_t *actions, *term, *term16; float *reward, *reward16;
     CHECK(hipMalloc(&actions, (size_t)n * launches)); CHECK(hipMalloc(&term, (size_t)n)); CHECK(hipMalloc(&term16, (size_t)n));
     CHECK(hipMalloc(&reward, (size_t)n * 4)); CHECK(hipMalloc(&reward16, (size_t)n * 4));

@@ -20,9 +20,9 @@ int main(int argc, char **argv)
     g2048::StepArgs a{};
     CHECK(hipMalloc(&a.st.boards, (size_t)n * 16));
     CHECK(hipMalloc(&a.st.last_record, (size_t)n * 16));
-    CHECK(hipMalloc(&a.st.ep_counters, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMalloc(&a.st.ep_counters, (size_t)(n / 64 + 16) * 32));
     CHECK(hipMemset(a.st.last_record, 0, (size_t)n * 16));
-    CHECK(hipMemset(a.st.ep_counters, 0, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMemset(a.st.ep_counters, 0, (size_t)(n / 64 + 16) * 32));
     uint8_t *actions, *term; float *reward;
     CHECK(hipMalloc(&actions, (size_t)n * launches));
     CHECK(hipMalloc(&term, (size_t)n * launches));
@@ -43,7 +43,7 @@ int main(int argc, char **argv)
         part[q].n = n / S; part[q].board_offset = q * (n / S);
         part[q].st.boards = a.st.boards + (size_t)q * (n / S);
         part[q].st.last_record = a.st.last_record + (size_t)q * (n / S);
-        part[q].st.ep_counters = a.st.ep_counters + (size_t)q * (n / S / 64) * 2;
+        part[q].st.ep_counters = a.st.ep_counters + (size_t)q * (n / S / 64) * g2048::kSlotWords;
     }
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));

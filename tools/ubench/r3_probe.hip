@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(BS) obs_kernel(const Flat p)
             record_episode_ends(sp, i, o.terminated, !o.legal, rec, episodes, illegal_ends);
             if (o.terminated)
                 reset_record(rec, o, w, tb);
-            flush_episode_counts(counters, episodes, illegal_ends);
+            flush_episode_counts(counters, episodes, illegal_ends, wave_sum_lane63(o.gain), 0ull);
         } else {
             rec.r[0] ^= action;
             o.gain = rec.r[1] & 0xffu;
@@ -192,9 +192,9 @@ int main(int argc, char **argv)
     StepArgs a{};
     CHECK(hipMalloc(&a.st.boards, (size_t)n * 16));
     CHECK(hipMalloc(&a.st.last_record, (size_t)n * 16));
-    CHECK(hipMalloc(&a.st.ep_counters, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMalloc(&a.st.ep_counters, (size_t)(n / 64 + 16) * 32));
     CHECK(hipMemset(a.st.last_record, 0, (size_t)n * 16));
-    CHECK(hipMemset(a.st.ep_counters, 0, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMemset(a.st.ep_counters, 0, (size_t)(n / 64 + 16) * 32));
     uint8_t *actions, *term; float *reward; uint8_t *obs;
     CHECK(hipMalloc(&actions, (size_t)n * launches));
     CHECK(hipMalloc(&term, (size_t)n * launches));
@@ -328,7 +328,7 @@ int main(int argc, char **argv)
                 h[q].n = n / 2; h[q].board_offset = q * (n / 2);
                 h[q].st.boards = a.st.boards + (size_t)q * (n / 2);
                 h[q].st.last_record = a.st.last_record + (size_t)q * (n / 2);
-                h[q].st.ep_counters = a.st.ep_counters + (size_t)q * (n / 2 / 64) * 2;
+                h[q].st.ep_counters = a.st.ep_counters + (size_t)q * (n / 2 / 64) * g2048::kSlotWords;
             }
             auto launch_half = [&](const StepArgs &x, hipStream_t s) {
                 const StepTail tail{x.terminated, x.st.last_record, nullptr, nullptr, nullptr, 0.0f, 0u, 1u, nullptr, 0u};

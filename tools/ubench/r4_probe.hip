@@ -1,0 +1,152 @@
+// r4_probe.hip -- round-4 A/B harness (measurement tool, not product): what the return accounting costs the step.
+// Interleaved in one process, 2^lg boards, HIP events around `launches` back-to-back launches over a ring of [R][n]
+// action / reward / terminated buffers, median over rounds:
+//   r3        the round-3 product kernel (commit 1a3ea8e: 2-word episode slots, no gain sum)
+//   r4        the current product kernel step_kernel<1,true,true,false> (4-word slots, six-DPP-add gain sum, always-store)
+//   r4-lds    the same step with the gain sum as ONE ds_add_u32 per lane to a zeroed word of the wave's LDS tables,
+//             read back by the storing lane (no DPP)
+//   r4-nosum  the same step with the 4-word slot but no gain sum at all (what the sum itself costs)
+// Usage: r4_probe [log2_boards] [rounds] [launches]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "_r3/g2048r3_kernels.hip"
+#include "../../gym-2048_amd/csrc/g2048_kernels.hip"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+using namespace g2048;
+
+// MODE 0: no gain sum; 1: DPP (= product); 2: LDS atomic
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
+           uint32_t seed_hi, uint32_t t_lo, uint32_t t_hi, uint32_t n, float *reward, const StepTail tail)
+{
+    __shared__ WaveTables s_tables[kBlock / 64];
+    StepArgs p{};
+    p.st.boards = boards;
+    p.st.last_record = tail.last_record;
+    p.st.ep_counters = ep_counters;
+    p.actions = actions;
+    p.reward = reward;
+    p.terminated = tail.terminated;
+    p.n = n;
+    p.auto_reset = tail.auto_reset;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    Board rec = load_board_nt(p.st.boards, i);
+    const uint2 tables_piece = load_tables_piece();
+    const EpisodeCounters counters = load_episode_counters(p, i);
+    const Words w = philox4x32_10(t_lo, t_hi, board_offset + i, 0u, seed_lo, seed_hi);
+    const uint32_t action = load_action<1>(p.actions, i, w.w[3]);
+    const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
+    const StepOut o = play_record(rec, action, w, 0u, tb);
+    uint32_t episodes = 0, illegal_ends = 0;
+    const unsigned long long done = record_episode_ends(p, i, o.terminated, !o.legal, rec, episodes, illegal_ends);
+    uint32_t wave_gain = 0;
+    uint32_t *acc = const_cast<uint32_t *>(&tb.t->pad[0]); // zero after staging (the image's pad words are 0)
+    if constexpr (MODE == 1)
+        wave_gain = wave_sum_lane63(o.gain);
+    else if constexpr (MODE == 2)
+        __hip_atomic_fetch_add(acc, o.gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const unsigned long long pending = pending_after_step(done, p.auto_reset);
+    if (o.terminated && p.auto_reset != 0)
+        reset_record(rec, o, w, tb);
+    store_board_nt(p.st.boards, i, rec);
+    __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : tail.illegal_reward, p.reward + i);
+    __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
+    if constexpr (MODE == 2) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((threadIdx.x & 63u) == 63u)
+            wave_gain = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending);
+}
+
+struct Variant { std::string name; std::function<void(uint32_t j, hipStream_t s)> launch; };
+
+int main(int argc, char **argv)
+{
+    const int lg = argc > 1 ? atoi(argv[1]) : 20;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 15;
+    const int launches = argc > 3 ? atoi(argv[3]) : 200;
+    const uint32_t n = 1u << lg, R = lg >= 24 ? 4 : 32;
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+    auto state = [&](uint4 *&boards, uint4 *&last, unsigned long long *&ctr) {
+        CHECK(hipMalloc(&boards, (size_t)n * 16)); CHECK(hipMalloc(&last, (size_t)n * 16)); CHECK(hipMalloc(&ctr, (size_t)(n / 64 + 16) * 32));
+        CHECK(hipMemset(boards, 0, (size_t)n * 16)); CHECK(hipMemset(last, 0, (size_t)n * 16)); CHECK(hipMemset(ctr, 0, (size_t)(n / 64 + 16) * 32));
+    };
+    const int NV = 4;
+    uint4 *boards[NV], *last[NV]; unsigned long long *ctr[NV];
+    for (int v = 0; v < NV; ++v) state(boards[v], last[v], ctr[v]);
+    uint8_t *actions, *term; float *reward;
+    CHECK(hipMalloc(&actions, (size_t)R * n)); CHECK(hipMalloc(&term, (size_t)R * n)); CHECK(hipMalloc(&reward, (size_t)R * n * 4));
+    CHECK(launch_fill_actions(actions, n, 0, 42u, 0u, 1000, R, s));
+    // initial state: reset + 64 aged steps with the product kernel, copied to every variant
+    StepArgs a{};
+    a.st.boards = boards[1]; a.st.last_record = last[1]; a.st.ep_counters = ctr[1];
+    a.n = n; a.seed_lo = 42u; a.t_lo = 0; a.auto_reset = 1; a.k_steps = 64;
+    CHECK(launch_reset(a, 0, nullptr, s));
+    a.t_lo = 1;
+    CHECK(launch_rollout_random(a, s));
+    CHECK(hipStreamSynchronize(s));
+    for (int v = 0; v < NV; ++v)
+        if (v != 1) CHECK(hipMemcpy(boards[v], boards[1], (size_t)n * 16, hipMemcpyDeviceToDevice));
+    const dim3 g(n / 256), b(256);
+    auto tail_of = [&](int v, uint32_t j) { return StepTail{term + (size_t)(j % R) * n, last[v], nullptr, nullptr, nullptr, 0.0f, 0u, 1u, nullptr, 0u, nullptr, nullptr, 0ull}; };
+    std::vector<Variant> vs;
+    vs.push_back({"r3 product (2-word slot, no sum)", [&](uint32_t j, hipStream_t st) {
+        const g2048r3::StepTail t{term + (size_t)(j % R) * n, last[0], nullptr, nullptr, nullptr, 0.0f, 0u, 1u, nullptr, 0u, nullptr, nullptr, 0ull};
+        hipLaunchKernelGGL((g2048r3::step_kernel<1, true, true, false>), g, b, 0, st, boards[0], (const void *)(actions + (size_t)(j % R) * n), ctr[0], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, t); }});
+    vs.push_back({"r4 product (DPP gain sum)", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((step_kernel<1, true, true, false>), g, b, 0, st, boards[1], (const void *)(actions + (size_t)(j % R) * n), ctr[1], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(1, j)); }});
+    vs.push_back({"r4-lds (ds_add gain sum)", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<2>), g, b, 0, st, boards[2], (const void *)(actions + (size_t)(j % R) * n), ctr[2], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(2, j)); }});
+    vs.push_back({"r4-nosum (4-word slot only)", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<0>), g, b, 0, st, boards[3], (const void *)(actions + (size_t)(j % R) * n), ctr[3], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(3, j)); }});
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<std::vector<double>> us(vs.size());
+    uint32_t j = 0;
+    for (int r = -2; r < rounds; ++r) {
+        for (size_t v = 0; v < vs.size(); ++v) {
+            CHECK(hipEventRecord(e0, s));
+            for (int l = 0; l < launches; ++l)
+                vs[v].launch(j + l, s);
+            CHECK(hipEventRecord(e1, s));
+            CHECK(hipStreamSynchronize(s));
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 0)
+                us[v].push_back(ms * 1e3 / launches);
+        }
+        j += launches; // every variant plays the same transactions
+    }
+    // cross-check: all variants must have played the same games; the three r4 flavours the same slots
+    std::vector<uint4> h0(n), h1(n);
+    CHECK(hipMemcpy(h0.data(), boards[1], (size_t)n * 16, hipMemcpyDeviceToHost));
+    for (int v = 0; v < NV; ++v) {
+        CHECK(hipMemcpy(h1.data(), boards[v], (size_t)n * 16, hipMemcpyDeviceToHost));
+        printf("boards of variant %d %s the product's\n", v, memcmp(h0.data(), h1.data(), (size_t)n * 16) == 0 ? "==" : "DIFFER FROM");
+    }
+    std::vector<unsigned long long> c1((size_t)n / 64 * 4), c2((size_t)n / 64 * 4);
+    CHECK(hipMemcpy(c1.data(), ctr[1], c1.size() * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(c2.data(), ctr[2], c2.size() * 8, hipMemcpyDeviceToHost));
+    printf("slots of r4-lds %s the product's\n", c1 == c2 ? "==" : "DIFFER FROM");
+    for (size_t v = 0; v < vs.size(); ++v) {
+        std::sort(us[v].begin(), us[v].end());
+        printf("%-36s 2^%d boards: median %7.3f us  min %7.3f  max %7.3f   (38 B/board: %.0f GB/s)\n", vs[v].name.c_str(), lg,
+               us[v][us[v].size() / 2], us[v].front(), us[v].back(), 38.0 * n / us[v][us[v].size() / 2] * 1e-3);
+    }
+    return 0;
+}

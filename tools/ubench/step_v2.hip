@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(BS) kern_flat(uint4 *boards, const void *actio
     store_board_nt(p.st.boards, i, rec);
     __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : p.illegal_reward, p.reward + i);
     __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
-    flush_episode_counts(counters, episodes, illegal_ends);
+    flush_episode_counts(counters, episodes, illegal_ends, wave_sum_lane63(o.gain), 0ull);
 }
 
 template <int BS>
@@ -312,9 +312,9 @@ int main(int argc, char **argv)
     g2048::StepArgs a2{};
     CHECK(hipMalloc(&a2.st.boards, (size_t)n * 16));
     CHECK(hipMalloc(&a2.st.last_record, (size_t)n * 64));
-    CHECK(hipMalloc(&a2.st.ep_counters, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMalloc(&a2.st.ep_counters, (size_t)(n / 64 + 16) * 32));
     CHECK(hipMemset(a2.st.last_record, 0, (size_t)n * 16));
-    CHECK(hipMemset(a2.st.ep_counters, 0, (size_t)(n / 64 + 16) * 16));
+    CHECK(hipMemset(a2.st.ep_counters, 0, (size_t)(n / 64 + 16) * 32));
     uint8_t *actions, *term; float *reward;
     CHECK(hipMalloc(&actions, (size_t)n * (launches + 1)));
     CHECK(hipMalloc(&term, (size_t)n * launches));
