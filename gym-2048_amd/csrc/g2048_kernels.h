@@ -14,10 +14,10 @@ struct DeviceState {
                         //     array -- self.score (game2048_env.py:86) = potential - deficit
     uint4 *last_record; // [n] record a board's most recent episode ENDED on (all-zero: none yet); its score is
                         //     that episode's return.  Written only by lanes whose episode ended.
-    unsigned long long *ep_counters; // one SLOT of kSlotWords uint64 per 64 boards: {finished episodes, of which ended on an
-                                     // illegal move, G = summed merge scores (return accounting), pending mask}; updated by
-                                     // ONE lane of the wavefront that owns the boards (old values via the scalar cache);
-                                     // layout and meaning in g2048_kernels.hip "episode SLOT"
+    unsigned long long *ep_counters; // one 32-byte SLOT per 64 boards: finished episodes, of which ended on an illegal move,
+                                     // G = summed merge scores (return accounting), pending mask -- as eight dwords, the
+                                     // four low halves first; updated by ONE lane of the wavefront that owns the boards
+                                     // (old values via the scalar cache); g2048_kernels.hip "episode SLOT"
     uint64_t *rng;      // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
     // numpy-RNG mode only (same allocation, behind the planes): the boards whose episode ended in the current step,
     // one list of up to 64 local board indices per wavefront of the step launch + its length.  The step kernel

@@ -180,33 +180,59 @@ __device__ __forceinline__ unsigned long long wave_sum64_lane63(unsigned long lo
            (static_cast<unsigned long long>(s2) << 44);
 }
 
-// ---- the wavefront's episode SLOT: four uint64 per 64 boards (g2048_kernels.h kSlotWords)
-//   [0] episodes      finished episodes
-//   [1] illegal_ends  ... of which ended on an illegal move
-//   [2] gain_sum      G: merge score of every move of these 64 boards since the statistics were cleared (+ the scores
-//                     they held then, -/+ what g2048_reset / g2048_set_scores took away or put in).  Conservation:
-//                     every point scored is either still on a live board or belongs to a finished episode, so
-//                         sum of the final scores of ALL finished episodes  =  G - sum of the live boards' scores
-//                     which the statistics kernel evaluates (g2048_stats.return_sum) -- exact, and no per-episode
-//                     work in the step: the step only adds its 64 gains (six DPP adds)
-//   [3] pending       bit l: board l's episode has ended and the board has NOT been reset (auto_reset == 0): its score
-//                     belongs to a finished episode although it is still in the record
+// ---- the wavefront's episode SLOT: 32 bytes per 64 boards (g2048_kernels.h kSlotWords), four 64-bit quantities
+//   episodes      finished episodes
+//   illegal_ends  ... of which ended on an illegal move
+//   gain_sum      G: merge score of every move of these 64 boards since the statistics were cleared (+ the scores
+//                 they held then, -/+ what g2048_reset / g2048_set_scores took away or put in).  Conservation:
+//                 every point scored is either still on a live board or belongs to a finished episode, so
+//                     sum of the final scores of ALL finished episodes  =  G - sum of the live boards' scores
+//                 which the statistics kernel evaluates (g2048_stats.return_sum) -- exact, and no per-episode
+//                 work in the step: the step only adds its 64 gains (six DPP adds)
+//   pending       bit l: board l's episode has ended and the board has NOT been reset (auto_reset == 0): its score
+//                 belongs to a finished episode although it is still in the record
+// stored as EIGHT DWORDS with the four LOW halves first: {episodes.lo, illegal_ends.lo, gain_sum.lo, pending.lo,
+// episodes.hi, illegal_ends.hi, gain_sum.hi, pending.hi}.  Sparse stores cost per DWORD on this chip (the 16-byte
+// terminal-record store of 7 % of the lanes costs 0.57 us per launch at 2^20 boards, a 4-byte one 0.11 us,
+// profiles/r02_g_ubench_2p20.txt; storing all eight dwords of the slot per launch measured +0.32 us against the two-word
+// slot of round 3, tools/ubench/r4_probe.hip), so a launch stores the THREE low counter dwords with one
+// global_store_dwordx3 and touches the rest only when it changes: the high halves on a carry (once in 2^32 counts), the
+// pending mask when it differs from the one that came in (never with auto_reset).
 // The slot is private to its wavefront (one wavefront per slot per launch, launches are stream-ordered), so it is
-// updated without atomics: the old values come in through the SCALAR cache (uniform address, loaded at kernel entry
-// -- no VALU, no vector-memory instruction, latency never exposed) and ONE lane -- lane 63, where the DPP sum of the
-// gains lands -- stores the new ones.  Measured against 64-bit atomics: -0.5 us per launch at 2^20 boards
+// updated without atomics: the old values come in through the SCALAR cache (uniform address, one s_load_dwordx8 at
+// kernel entry -- no VALU, no vector-memory instruction, latency never exposed) and ONE lane -- lane 63, where the DPP
+// sum of the gains lands -- stores the new ones.  Measured against 64-bit atomics: -0.5 us per launch at 2^20 boards
 // (profiles/r02_g_ubench_2p20.txt).
 struct EpisodeCounters {
-    unsigned long long *slot;
-    unsigned long long episodes, illegal_ends, gain_sum;
+    uint32_t *slot;
+    uint32_t ep_lo, ill_lo, gain_lo, pend_lo, ep_hi, ill_hi, gain_hi, pend_hi;
 };
+
+__device__ __forceinline__ uint32_t *slot_of(unsigned long long *ep_counters, uint32_t wave_id)
+{
+    return reinterpret_cast<uint32_t *>(ep_counters + kSlotWords * wave_id);
+}
 
 __device__ __forceinline__ EpisodeCounters load_episode_counters(const StepArgs &p, uint32_t i_raw)
 {
-    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(i_raw >> 6);
-    unsigned long long *slot = p.st.ep_counters + kSlotWords * wave_id;
-    return EpisodeCounters{slot, slot[0], slot[1], slot[2]};
+    uint32_t *slot = slot_of(p.st.ep_counters, __builtin_amdgcn_readfirstlane(i_raw >> 6));
+    const uint4 lo = *reinterpret_cast<const uint4 *>(slot), hi = *reinterpret_cast<const uint4 *>(slot + 4);
+    return EpisodeCounters{slot, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 }
+
+// 64-bit views of a slot for the kernels off the hot path
+__device__ __forceinline__ unsigned long long slot_get(const uint32_t *slot, uint32_t k)
+{
+    return static_cast<unsigned long long>(slot[k]) | (static_cast<unsigned long long>(slot[4u + k]) << 32);
+}
+
+__device__ __forceinline__ void slot_set(uint32_t *slot, uint32_t k, unsigned long long v)
+{
+    slot[k] = static_cast<uint32_t>(v);
+    slot[4u + k] = static_cast<uint32_t>(v >> 32);
+}
+
+enum : uint32_t { kSlotEpisodes = 0, kSlotIllegal = 1, kSlotGain = 2, kSlotPending = 3 };
 
 // gain_lane63: the wave's summed merge score of this launch, valid in lane 63 (wave_sum_lane63 / wave_sum64_lane63);
 // pending: the new pending mask (wave-uniform).
@@ -215,13 +241,23 @@ __device__ __forceinline__ void flush_episode_counts(const EpisodeCounters &c, u
 {
     if ((threadIdx.x & 63u) != 63u)
         return;
-    ulonglong2 v, g;
-    v.x = c.episodes + episodes; // (wave-uniform: scalar adds)
-    v.y = c.illegal_ends + illegal_ends;
-    g.x = c.gain_sum + gain_lane63;
-    g.y = pending;
-    *reinterpret_cast<ulonglong2 *>(c.slot) = v;
-    *reinterpret_cast<ulonglong2 *>(c.slot + 2) = g;
+    const unsigned long long ep = (static_cast<unsigned long long>(c.ep_hi) << 32 | c.ep_lo) + episodes;      // scalar
+    const unsigned long long ill = (static_cast<unsigned long long>(c.ill_hi) << 32 | c.ill_lo) + illegal_ends; // scalar
+    const unsigned long long gain = (static_cast<unsigned long long>(c.gain_hi) << 32 | c.gain_lo) + gain_lane63;
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const u32x3 lo = {static_cast<uint32_t>(ep), static_cast<uint32_t>(ill), static_cast<uint32_t>(gain)};
+    *reinterpret_cast<u32x3 *>(c.slot) = lo;                                           // the common case: 12 bytes
+    const uint32_t ep_hi = static_cast<uint32_t>(ep >> 32), ill_hi = static_cast<uint32_t>(ill >> 32),
+                   gain_hi = static_cast<uint32_t>(gain >> 32);
+    if (ep_hi != c.ep_hi || ill_hi != c.ill_hi || gain_hi != c.gain_hi) {             // a carry: once in 2^32 counts
+        const u32x3 hi = {ep_hi, ill_hi, gain_hi};
+        *reinterpret_cast<u32x3 *>(c.slot + 4) = hi;
+    }
+    const uint32_t pend_lo = static_cast<uint32_t>(pending), pend_hi = static_cast<uint32_t>(pending >> 32);
+    if (pend_lo != c.pend_lo || pend_hi != c.pend_hi) {                                // only without auto_reset
+        c.slot[3] = pend_lo;
+        c.slot[7] = pend_hi;
+    }
 }
 
 // "episode ended and not reset" mask of a step launch from the mask of the lanes whose episode ended: every board was
@@ -241,15 +277,15 @@ __device__ __forceinline__ void adjust_slot(unsigned long long *ep_counters, uin
     const uint32_t total = wave_sum_lane63(static_cast<uint32_t>(delta)); // |sum| <= 64 * 2^24: fits int32
     const unsigned long long cleared = __builtin_amdgcn_ballot_w64(clear);
     if ((threadIdx.x & 63u) == 63u) {
-        unsigned long long *slot = ep_counters + kSlotWords * (i_raw >> 6);
-        slot[2] += static_cast<unsigned long long>(static_cast<long long>(static_cast<int32_t>(total)));
-        slot[3] &= ~cleared;
+        uint32_t *slot = slot_of(ep_counters, i_raw >> 6);
+        slot_set(slot, kSlotGain, slot_get(slot, kSlotGain) + static_cast<unsigned long long>(static_cast<long long>(static_cast<int32_t>(total))));
+        slot_set(slot, kSlotPending, slot_get(slot, kSlotPending) & ~cleared);
     }
 }
 
-__device__ __forceinline__ bool is_pending(const unsigned long long *ep_counters, uint32_t i_raw)
+__device__ __forceinline__ bool is_pending(unsigned long long *ep_counters, uint32_t i_raw)
 {
-    const unsigned long long pending = ep_counters[kSlotWords * __builtin_amdgcn_readfirstlane(i_raw >> 6) + 3u];
+    const unsigned long long pending = slot_get(slot_of(ep_counters, __builtin_amdgcn_readfirstlane(i_raw >> 6)), kSlotPending);
     return ((pending >> (threadIdx.x & 63u)) & 1ull) != 0ull;
 }
 
@@ -920,11 +956,11 @@ __global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState s
     }
     const uint32_t total = wave_sum_lane63(score); // <= 64 * (2^24 - 1)
     if ((threadIdx.x & 63u) == 63u) {
-        unsigned long long *slot = st.ep_counters + kSlotWords * (i_raw >> 6);
-        slot[0] = 0ull;
-        slot[1] = 0ull;
-        slot[2] = total;
-        slot[3] = 0ull;
+        uint32_t *slot = slot_of(st.ep_counters, i_raw >> 6);
+        slot_set(slot, kSlotEpisodes, 0ull);
+        slot_set(slot, kSlotIllegal, 0ull);
+        slot_set(slot, kSlotGain, total);
+        slot_set(slot, kSlotPending, 0ull);
     }
 }
 
@@ -1141,16 +1177,17 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
     __syncthreads();
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t wv = blockIdx.x * kBlock + tid; wv < n_waves; wv += stride) {
-        const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(st.ep_counters + kSlotWords * wv);
-        episodes += c.x;
-        illegal += c.y;
-        ret += st.ep_counters[kSlotWords * wv + 2u];
+        const uint32_t *slot = slot_of(st.ep_counters, wv);
+        const uint4 lo = *reinterpret_cast<const uint4 *>(slot), hi = *reinterpret_cast<const uint4 *>(slot + 4);
+        episodes += static_cast<unsigned long long>(hi.x) << 32 | lo.x;
+        illegal += static_cast<unsigned long long>(hi.y) << 32 | lo.y;
+        ret += static_cast<unsigned long long>(hi.z) << 32 | lo.z;
     }
     // whole wavefronts iterate together (the ballots need every lane's vote): lanes past the end vote "none"
     for (uint64_t base = blockIdx.x * kBlock + tid - lane; base < n; base += stride) { // 64-bit: n may be near 2^32
         const uint64_t i = base + lane;
         // boards whose episode has ended but which were not reset (auto_reset == 0): their score is a finished episode's
-        const unsigned long long pending = st.ep_counters[kSlotWords * (base >> 6) + 3u]; // uniform address: scalar load
+        const unsigned long long pending = slot_get(slot_of(st.ep_counters, static_cast<uint32_t>(base >> 6)), kSlotPending); // uniform: scalar loads
         uint32_t h = 0xffu;
         if (i < n) {
             const Board live = load_board_nt(st.boards, static_cast<uint32_t>(i));

@@ -3,9 +3,10 @@
 // action / reward / terminated buffers, median over rounds:
 //   r3        the round-3 product kernel (commit 1a3ea8e: 2-word episode slots, no gain sum)
 //   r4        the current product kernel step_kernel<1,true,true,false> (4-word slots, six-DPP-add gain sum, always-store)
-//   r4-lds    the same step with the gain sum as ONE ds_add_u32 per lane to a zeroed word of the wave's LDS tables,
-//             read back by the storing lane (no DPP)
-//   r4-nosum  the same step with the 4-word slot but no gain sum at all (what the sum itself costs)
+//   r4-nosum  the same step with the 8-dword slot but no gain sum at all (what the sum itself costs)
+//   r4-noterm the product step without the sparse 16-byte terminal-record store (what per-board last returns cost)
+// (A variant with the gain sum as one ds_add_u32 per lane to a zeroed LDS word measured 10.60 us against 10.36 for the
+// DPP form at 2^20 boards and its sums did not cross-check: dropped, profiles/r04_b_r4_probe_2p20.txt.)
 // Usage: r4_probe [log2_boards] [rounds] [launches]
 #include <hip/hip_runtime.h>
 
@@ -25,7 +26,7 @@
 
 using namespace g2048;
 
-// MODE 0: no gain sum; 1: DPP (= product); 2: LDS atomic
+// MODE 0: no gain sum; 1: DPP (= product); 3: DPP, no terminal-record store
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
@@ -50,25 +51,23 @@ probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, 
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
     const StepOut o = play_record(rec, action, w, 0u, tb);
     uint32_t episodes = 0, illegal_ends = 0;
-    const unsigned long long done = record_episode_ends(p, i, o.terminated, !o.legal, rec, episodes, illegal_ends);
+    unsigned long long done;
+    if constexpr (MODE == 3) {
+        done = __builtin_amdgcn_ballot_w64(o.terminated);
+        episodes = static_cast<uint32_t>(__popcll(done));
+        illegal_ends = static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(o.terminated && !o.legal)));
+    } else {
+        done = record_episode_ends(p, i, o.terminated, !o.legal, rec, episodes, illegal_ends);
+    }
     uint32_t wave_gain = 0;
-    uint32_t *acc = const_cast<uint32_t *>(&tb.t->pad[0]); // zero after staging (the image's pad words are 0)
-    if constexpr (MODE == 1)
+    if constexpr (MODE != 0)
         wave_gain = wave_sum_lane63(o.gain);
-    else if constexpr (MODE == 2)
-        __hip_atomic_fetch_add(acc, o.gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     const unsigned long long pending = pending_after_step(done, p.auto_reset);
     if (o.terminated && p.auto_reset != 0)
         reset_record(rec, o, w, tb);
     store_board_nt(p.st.boards, i, rec);
     __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : tail.illegal_reward, p.reward + i);
     __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
-    if constexpr (MODE == 2) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((threadIdx.x & 63u) == 63u)
-            wave_gain = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
     flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending);
 }
 
@@ -101,18 +100,22 @@ int main(int argc, char **argv)
     CHECK(launch_rollout_random(a, s));
     CHECK(hipStreamSynchronize(s));
     for (int v = 0; v < NV; ++v)
-        if (v != 1) CHECK(hipMemcpy(boards[v], boards[1], (size_t)n * 16, hipMemcpyDeviceToDevice));
+        if (v != 1) {
+            CHECK(hipMemcpy(boards[v], boards[1], (size_t)n * 16, hipMemcpyDeviceToDevice));
+            if (v != 0) // (the round-3 kernel has its own 2-word slot layout)
+                CHECK(hipMemcpy(ctr[v], ctr[1], (size_t)(n / 64 + 16) * 32, hipMemcpyDeviceToDevice));
+        }
     const dim3 g(n / 256), b(256);
     auto tail_of = [&](int v, uint32_t j) { return StepTail{term + (size_t)(j % R) * n, last[v], nullptr, nullptr, nullptr, 0.0f, 0u, 1u, nullptr, 0u, nullptr, nullptr, 0ull}; };
     std::vector<Variant> vs;
     vs.push_back({"r3 product (2-word slot, no sum)", [&](uint32_t j, hipStream_t st) {
         const g2048r3::StepTail t{term + (size_t)(j % R) * n, last[0], nullptr, nullptr, nullptr, 0.0f, 0u, 1u, nullptr, 0u, nullptr, nullptr, 0ull};
         hipLaunchKernelGGL((g2048r3::step_kernel<1, true, true, false>), g, b, 0, st, boards[0], (const void *)(actions + (size_t)(j % R) * n), ctr[0], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, t); }});
-    vs.push_back({"r4 product (DPP gain sum)", [&](uint32_t j, hipStream_t st) {
+    vs.push_back({"r4 product (DPP sum, 3-dword store)", [&](uint32_t j, hipStream_t st) {
         hipLaunchKernelGGL((step_kernel<1, true, true, false>), g, b, 0, st, boards[1], (const void *)(actions + (size_t)(j % R) * n), ctr[1], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(1, j)); }});
-    vs.push_back({"r4-lds (ds_add gain sum)", [&](uint32_t j, hipStream_t st) {
-        hipLaunchKernelGGL((probe_step<2>), g, b, 0, st, boards[2], (const void *)(actions + (size_t)(j % R) * n), ctr[2], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(2, j)); }});
-    vs.push_back({"r4-nosum (4-word slot only)", [&](uint32_t j, hipStream_t st) {
+    vs.push_back({"r4-noterm (no terminal-record store)", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<3>), g, b, 0, st, boards[2], (const void *)(actions + (size_t)(j % R) * n), ctr[2], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(2, j)); }});
+    vs.push_back({"r4-nosum (slot, no gain sum)", [&](uint32_t j, hipStream_t st) {
         hipLaunchKernelGGL((probe_step<0>), g, b, 0, st, boards[3], (const void *)(actions + (size_t)(j % R) * n), ctr[3], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(3, j)); }});
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -142,7 +145,7 @@ int main(int argc, char **argv)
     std::vector<unsigned long long> c1((size_t)n / 64 * 4), c2((size_t)n / 64 * 4);
     CHECK(hipMemcpy(c1.data(), ctr[1], c1.size() * 8, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(c2.data(), ctr[2], c2.size() * 8, hipMemcpyDeviceToHost));
-    printf("slots of r4-lds %s the product's\n", c1 == c2 ? "==" : "DIFFER FROM");
+    printf("slots of r4-noterm %s the product's\n", c1 == c2 ? "==" : "DIFFER FROM");
     for (size_t v = 0; v < vs.size(); ++v) {
         std::sort(us[v].begin(), us[v].end());
         printf("%-36s 2^%d boards: median %7.3f us  min %7.3f  max %7.3f   (38 B/board: %.0f GB/s)\n", vs[v].name.c_str(), lg,
