@@ -294,7 +294,12 @@ def main():
 
     B, K, W = args.boards, args.steps, args.warmup
     shard = weak_shard(B, rank, world)
-    eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset)
+    # Episode bookkeeping of the benchmarked engine: what the once-per-rollout exchange needs.  --gather summary ships
+    # episodes / illegal ends / the exact return sum, none of which needs the per-board terminal records, so they are
+    # off (g2048_set_last_records: one sparse 16-byte store per finished episode less; extras.with_last_records has the
+    # same launch train with them on); --gather full ships every board's last return and keeps them.
+    keep_last = args.gather == "full"
+    eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset, last_records=keep_last)
     eng.reset()
     # State preparation (not timed, not counted as warm-up steps): SURVEY 8d defines the workload as ">= 1 000 steps
     # after >= 50 warm-up steps".  Right after a reset every board is two tiles old and a random move is illegal far
@@ -420,6 +425,10 @@ def main():
                                      f"before anything is measured") if args.device_warmup > 0 else "none",
                    "path": "one step_kernel launch per env-step (g2048_rollout), actions/reward/terminated in "
                            "[K][B] HBM rollout buffers, auto-reset fused",
+                   "episode_bookkeeping": ("per-wavefront counters + exact return sum (g2048_stats.return_sum); per-board "
+                                           "terminal records " + ("ON (--gather full reads them)" if keep_last else
+                                                                  "OFF (g2048_set_last_records(0): not needed by the summary exchange; "
+                                                                  "extras.with_last_records times the same train with them on)")),
                    "collective": (f"none per step; one all-gather per rollout of the "
                                   + (f"per-rank episodic-return summaries (g2048_stats, {stats_bytes} B each)" if args.gather == "summary" else "per-board episodic returns (int32[B] each)")
                                   if dist_on else "none")},
@@ -445,8 +454,9 @@ def main():
                            "end-to-host-visible latency of the closing bracket)"},
         "episodes_finished": int(stats["episodes"]), "return_sum": int(stats["return_sum"]),
         "mean_episode_score": stats["mean_episode_score"],        # exact: over ALL finished episodes of this rank's shard
-        "mean_last_episode_score": stats["mean_last_score"],      # over each board's most recent finished episode
     }
+    if keep_last:
+        out["mean_last_episode_score"] = stats["mean_last_score"]   # over each board's most recent finished episode
     if force_dist and world == 1:
         out["config"]["forced_dist"] = f"one-rank {backend} process group: the N > 1 code path on one GPU"
         out["config"]["collective"] = "one-rank all-gather of the episodic-return summary (forced)" 
@@ -496,6 +506,32 @@ def main():
             del fa, fr, ft, fplan
         except Exception as exc:  # pragma: no cover
             extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
+        # (a2b) the timed launch train on an engine that KEEPS the per-board terminal records (the library's default):
+        #       what g2048_get_last_scores / --gather full cost the step
+        try:
+            other = Batched2048(B, device=local_rank, seed=SEED, last_records=not keep_last)
+            other.reset()
+            other.rollout_random(AGE_STEPS)
+            kk = min(K, 100)
+            oplan = other.prepare_rollout(actions[:kk], reward=reward[:kk], terminated=terminated[:kk])
+            oplan.run()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                oplan.run()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / kk
+                best = us if best is None else min(best, us)
+            extras["with_last_records" if not keep_last else "without_last_records"] = {
+                "launch_us": best, "steps_per_s": B / (best * 1e-6), "launches": kk,
+                "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * B / (best * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            other.close()
+            del other, oplan
+        except Exception as exc:  # pragma: no cover
+            extras["with_last_records"] = {"error": str(exc)}
         # (a3) the env-step INCLUDING the observation the reference's step() returns (stack(), game2048_env.py:100):
         #      ONE launch per step -- step_kernel<.., HAS_OBS> writes the uint8 [B,16,4,4] one-hot of the record it
         #      leaves behind (+256 B per env-step, 294 B in all) -- through g2048_rollout over [Ko,B,16,4,4]

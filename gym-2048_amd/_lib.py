@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class G2048Error(RuntimeError):
@@ -101,6 +101,8 @@ SIGNATURES = {
     "g2048_get_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_set_scores": (C.c_int, [_E, C.c_void_p, _S]),
     "g2048_get_last_scores": (C.c_int, [_E, C.c_void_p, _S]),
+    "g2048_set_last_records": (C.c_int, [_E, C.c_int, _S]),
+    "g2048_get_last_records": (C.c_int, [_E]),
     "g2048_records_ptr": (C.c_void_p, [_E]),
     "g2048_last_records_ptr": (C.c_void_p, [_E]),
     "g2048_episode_stats": (C.c_int, [_E, C.POINTER(Stats), _S]),

@@ -65,7 +65,7 @@ class Batched2048:
     """
 
     def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
-                 illegal_move_reward: float = 0.0, max_tile=None, rng: str = "philox"):
+                 illegal_move_reward: float = 0.0, max_tile=None, rng: str = "philox", last_records: bool = True):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         if not torch.cuda.is_available():
@@ -93,6 +93,8 @@ class Batched2048:
         self.highest = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.terminal_boards = torch.zeros((n, 16), dtype=torch.uint8, device=dev)
         self._boards_view = None
+        if not last_records:
+            self.set_last_records(False)
         if self.rng_mode == "numpy":
             self.seed(seed)
 
@@ -127,6 +129,17 @@ class Batched2048:
         exp = max_tile_to_exp(max_tile)
         self.max_tile = max_tile
         check(self._lib.g2048_set_max_tile(self._h, exp))
+
+    def set_last_records(self, enable: bool):
+        """Keep (default) or stop keeping the terminal record of every board's most recent finished episode
+        (``g2048_set_last_records``): with it off a step skips one sparse 16-byte store per finished episode
+        (-0.85 us per launch at 2^20 boards); ``last_scores`` / ``last_records`` / the ``last_*`` statistics then are
+        unavailable, ``episodes`` / ``illegal_ends`` / the exact ``return_sum`` are not affected."""
+        check(self._lib.g2048_set_last_records(self._h, int(bool(enable)), self._stream()))
+
+    @property
+    def last_records_enabled(self) -> bool:
+        return bool(self._lib.g2048_get_last_records(self._h))
 
     def seed(self, seed: int):
         """Seeding half of ``reset(seed=...)`` (game2048_env.py:103)."""
@@ -327,6 +340,8 @@ class Batched2048:
     def last_records(self) -> torch.Tensor:
         """Zero-copy ``uint8 [n, 16]``: the record each board's most recent episode ended on (all-zero: none)."""
         ptr = self._lib.g2048_last_records_ptr(self._h)
+        if not ptr:
+            raise G2048Error("this engine does not keep terminal records (set_last_records(True) turns them on)")
         return torch.as_tensor(_DeviceView(ptr, (self.n_envs, 16), "|u1"), device=self.device)
 
     def tile_values(self) -> torch.Tensor:

@@ -65,6 +65,7 @@ struct g2048_engine {
     // completion word (its own 64-byte pinned, device-mapped, coherent block): published by the device, polled by the host
     unsigned long long *done_host = nullptr, *done_dev = nullptr;
     unsigned long long done_count = 0;
+    int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
 };
@@ -85,6 +86,8 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
 {
     g2048::StepArgs a{};
     a.st = e->st;
+    if (!e->track_last)
+        a.st.last_record = nullptr; // the kernels skip the terminal-record store
     if (io) {
         a.actions = io->actions;
         a.reward = io->reward;
@@ -106,6 +109,23 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
     a.max_exp = e->max_exp;
     a.auto_reset = auto_reset ? 1u : 0u;
     return a;
+}
+
+// the device state as the kernels should see it: no terminal-record array when the engine does not keep them
+g2048::DeviceState tracked_state(const g2048_engine *e)
+{
+    g2048::DeviceState st = e->st;
+    if (!e->track_last)
+        st.last_record = nullptr;
+    return st;
+}
+
+int need_last_records(const g2048_engine *e, const char *what)
+{
+    if (e->track_last)
+        return G2048_OK;
+    return fail(G2048_ERR_INVALID, "%s reads the boards' terminal records, which this engine does not keep "
+                                   "(g2048_set_last_records(e, 1, stream) turns them on)", what);
 }
 
 size_t obs_board_bytes(int dtype) { return static_cast<size_t>(256) << (dtype < 0 ? 0 : dtype); } // 16 channels x 16 cells
@@ -149,7 +169,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 10; }
+int g2048_abi_version(void) { return 11; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -249,8 +269,24 @@ int g2048_seed(g2048_engine *e, uint64_t seed, void *stream)
     // episode statistics restart with the stream: cleared by a kernel ON THE CALLER'S STREAM, so the
     // clear is ordered against step kernels already enqueued there
     G2048_HIP(hipSetDevice(e->device));
-    G2048_HIP(g2048::launch_clear_stats(e->st, static_cast<uint32_t>(e->n), static_cast<hipStream_t>(stream)));
+    G2048_HIP(g2048::launch_clear_stats(tracked_state(e), static_cast<uint32_t>(e->n), static_cast<hipStream_t>(stream)));
     return G2048_OK;
+}
+
+int g2048_set_last_records(g2048_engine *e, int enable, void *stream)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    G2048_HIP(hipSetDevice(e->device));
+    if (enable && !e->track_last) // records from before the pause would be stale: start from "none yet"
+        G2048_HIP(hipMemsetAsync(e->st.last_record, 0, e->n * 16, static_cast<hipStream_t>(stream)));
+    e->track_last = enable ? 1 : 0;
+    return G2048_OK;
+}
+
+int g2048_get_last_records(const g2048_engine *e)
+{
+    return e ? e->track_last : 0;
 }
 
 int g2048_get_clock(const g2048_engine *e, uint64_t *t)
@@ -887,6 +923,8 @@ int g2048_get_last_scores(const g2048_engine *ce, int32_t *buf, void *stream)
     g2048_engine *e = const_cast<g2048_engine *>(ce);
     if (!e || !buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
+    if (int rc = need_last_records(e, "g2048_get_last_scores"))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t n = static_cast<uint32_t>(e->n);
@@ -903,7 +941,7 @@ int g2048_get_last_scores(const g2048_engine *ce, int32_t *buf, void *stream)
 }
 
 void *g2048_records_ptr(const g2048_engine *e) { return e ? e->st.boards : nullptr; }
-void *g2048_last_records_ptr(const g2048_engine *e) { return e ? e->st.last_record : nullptr; }
+void *g2048_last_records_ptr(const g2048_engine *e) { return e && e->track_last ? e->st.last_record : nullptr; }
 
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
 {
@@ -911,7 +949,7 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, e->stats_dev, false, s));
+    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, e->stats_dev, false, s));
     g2048::StatsOut h{};
     G2048_HIP(hipMemcpyAsync(&h, e->stats_dev, sizeof h, hipMemcpyDeviceToHost, s));
     G2048_HIP(hipStreamSynchronize(s));
@@ -935,7 +973,7 @@ static int stats_async(const g2048_engine *e, g2048_stats *device_out, bool retu
     if (!is_device_ptr(device_out))
         return fail(G2048_ERR_INVALID, "the asynchronous statistics need a DEVICE buffer (use g2048_episode_stats for a host struct)");
     G2048_HIP(hipSetDevice(e->device));
-    G2048_HIP(g2048::launch_stats(e->st, static_cast<uint32_t>(e->n), e->stats_partials, reinterpret_cast<g2048::StatsOut *>(device_out),
+    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, reinterpret_cast<g2048::StatsOut *>(device_out),
                                   returns_only, static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
@@ -1031,7 +1069,7 @@ int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream)
     if (!e || !host_buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     StateHeader h{kStateMagic, e->n, e->seed, e->board_offset, e->t, e->fresh, e->max_exp, e->illegal_reward,
-                  e->st.rng ? 1u : 0u};
+                  (e->st.rng ? 1u : 0u) | (e->track_last ? 0u : 2u)}; // flags: 1 = numpy-RNG planes follow, 2 = no terminal records
     std::memcpy(host_buf, &h, sizeof h);
     char *body = static_cast<char *>(host_buf) + sizeof h;
     if (int rc = copy_out(e, body, e->slab, e->slab_bytes, stream))
@@ -1052,7 +1090,7 @@ int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, 
     if (h.magic != kStateMagic || h.n != e->n)
         return fail(G2048_ERR_INVALID, "state blob does not match this engine (magic %llx, n %llu vs %llu)",
                     (unsigned long long)h.magic, (unsigned long long)h.n, (unsigned long long)e->n);
-    const uint64_t want = sizeof(StateHeader) + e->slab_bytes + (h.reserved ? e->n * 40 : 0);
+    const uint64_t want = sizeof(StateHeader) + e->slab_bytes + ((h.reserved & 1u) ? e->n * 40 : 0);
     if (blob_bytes != want)
         return fail(G2048_ERR_INVALID, "state blob is %llu bytes, this engine's state is %llu",
                     (unsigned long long)blob_bytes, (unsigned long long)want);
@@ -1065,10 +1103,11 @@ int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, 
     e->fresh = h.fresh;
     e->max_exp = h.max_exp;
     e->illegal_reward = h.illegal_reward;
+    e->track_last = (h.reserved & 2u) ? 0 : 1;
     const char *body = static_cast<const char *>(host_buf) + sizeof h;
     if (int rc = copy_in(e, e->slab, body, e->slab_bytes, stream))
         return rc;
-    if (h.reserved) // the blob carries numpy-RNG planes
+    if (h.reserved & 1u) // the blob carries numpy-RNG planes
         return g2048_set_numpy_rng(e, reinterpret_cast<const uint64_t *>(body + e->slab_bytes), stream);
     return g2048_set_numpy_rng(e, nullptr, stream);
 }
@@ -1230,6 +1269,8 @@ int g2048_allgather_returns(const g2048_engine *ce, g2048_comm *c, int32_t *out,
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (c->device != e->device)
         return fail(G2048_ERR_INVALID, "communicator is on device %d, engine on device %d", c->device, e->device);
+    if (int rc = need_last_records(e, "g2048_allgather_returns"))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     if (int rc = ensure_returns(e))
         return rc;
@@ -1298,6 +1339,8 @@ int g2048_allgather_returns_local(g2048_comm_local *c, g2048_engine *const *engi
         if (engines[r]->device != c->devices[r])
             return fail(G2048_ERR_INVALID, "engine %d is on device %d, the communicator's slot %d on device %d", r,
                         engines[r]->device, r, c->devices[r]);
+        if (int rc = need_last_records(engines[r], "g2048_allgather_returns_local"))
+            return rc;
         if (engines[r]->n != engines[0]->n)
             return fail(G2048_ERR_INVALID, "engines must hold equal shards (engine %d has %llu boards, engine 0 %llu)", r,
                         (unsigned long long)engines[r]->n, (unsigned long long)engines[0]->n);

@@ -11,7 +11,9 @@
 // and that is also all a step moves for a board whose episode goes on: the episodic score travels
 // inside the 16-byte record (g2048_device.h "board RECORD").  A board whose episode ENDS additionally
 // writes its terminal record to last_record (sparse 16-byte store; the episode's return is computed
-// from it when somebody asks), and a wavefront that finished episodes bumps two counters.
+// from it when somebody asks) unless the engine was told not to keep them (g2048_set_last_records: 0.85 us
+// of a 10.2 us launch at 2^20 boards, tools/ubench/r4_probe.hip), and every wavefront adds its counts and the
+// merge scores of its 64 moves to its 32-byte slot (12 bytes stored per launch).
 #include "g2048_kernels.h"
 
 #include "g2048_device.h"
@@ -146,7 +148,8 @@ __device__ __forceinline__ unsigned long long record_episode_ends(const StepArgs
     if (done == 0ull)
         return 0ull;
     if (fin) {
-        store_board(p.st.last_record, i, terminal);
+        if (p.st.last_record) // (wave-uniform; NULL = the engine does not keep terminal records, g2048_set_last_records)
+            store_board(p.st.last_record, i, terminal);
         if (p.terminal_boards)
             store_board(p.terminal_boards, i, record_cells(terminal));
     }
@@ -951,7 +954,8 @@ __global__ void __launch_bounds__(kBlock) clear_stats_kernel(const DeviceState s
     const bool valid = i_raw < n;
     uint32_t score = 0;
     if (valid) {
-        st.last_record[i_raw] = make_uint4(0u, 0u, 0u, 0u);
+        if (st.last_record)
+            st.last_record[i_raw] = make_uint4(0u, 0u, 0u, 0u);
         score = record_score(load_board(st.boards, i_raw));
     }
     const uint32_t total = wave_sum_lane63(score); // <= 64 * (2^24 - 1)
@@ -1196,7 +1200,9 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
             if constexpr (FULL_STATS) {
                 h = highest(record_cells(live));
                 max_exp = max(max_exp, h);
-                const Board last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
+                Board last{{0u, 0u, 0u, 0u}};
+                if (st.last_record) // NULL: terminal records are not kept, last_* stay zero
+                    last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
                 if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
                     const unsigned int sc = record_score(last);
                     count += 1;

@@ -255,6 +255,16 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream);
  * turns the records into scores (potential - deficit) with a kernel. */
 int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream);
 
+/* Per-board "last finished episode" bookkeeping on / off (default: on).  On: a step that ends an episode stores the
+ * board's 16-byte terminal record (one sparse store per finished episode: 0.85 us of a 10.2 us launch at 2^20 boards
+ * under a random policy), which is what g2048_get_last_scores, g2048_last_records_ptr, g2048_allgather_returns and
+ * the last_* members of g2048_stats read.  Off: those calls fail with G2048_ERR_INVALID (the pointer is NULL, last_* are
+ * zero); episodes, illegal_ends and the exact return_sum -- everything the once-per-rollout exchange of a multi-GPU job
+ * needs -- do not depend on it.  Switching it on again clears the stored records (enqueued on `stream`).
+ * No counterpart in the reference, whose env keeps no episode history at all (SB3's Monitor does, on the host). */
+int g2048_set_last_records(g2048_engine *e, int enable, void *stream);
+int g2048_get_last_records(const g2048_engine *e);
+
 /* Raw device pointers of the engine-owned state for zero-copy views: the board RECORDS
  * (uint8[n][16]; cell = byte & 0x1f, see "RECORD" above) and the terminal records of the most recent
  * finished episodes (same format, all-zero = none yet).  Valid until g2048_destroy. */

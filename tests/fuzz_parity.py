@@ -40,7 +40,8 @@ def check_state(eng, ora, where, always_auto_reset=False):
     n = eng.n_envs
     assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards), where
     assert np.array_equal(eng.get_scores(), ora.score), where
-    assert np.array_equal(eng.get_last_scores(), ora.last_score), where
+    if eng.last_records_enabled:
+        assert np.array_equal(eng.get_last_scores(), ora.last_score), where
     st = eng.episode_stats()
     assert st["episodes"] == int(ora.ep_count.sum()), where
     assert st["return_sum"] == ora.return_sum, (where, st["return_sum"], ora.return_sum, ora.finished_return_sum)
@@ -61,8 +62,9 @@ def one_case(case):
     numpy_mode = bool(rs.random() < 0.2)       # the reference's own PCG64 per board (separate kernels)
     if numpy_mode:
         n, seed, offset = min(n, 1500), seed % (1 << 40), offset % (1 << 20)
+    keep_last = bool(rs.random() < 0.75)       # per-board terminal records on / off (g2048_set_last_records)
     eng = Batched2048(n, seed=seed, board_offset=offset, illegal_move_reward=irw, max_tile=max_tile,
-                      rng="numpy" if numpy_mode else "philox")
+                      rng="numpy" if numpy_mode else "philox", last_records=keep_last)
     ora = OracleBatch(n, seed, offset)
     ora.illegal_move_reward = irw
     ora.max_exp = 0 if max_tile is None else max_tile.bit_length() - 1
@@ -161,6 +163,7 @@ def one_case(case):
             other.load_state_dict(blob)
             eng.close()
             eng = other
+            assert eng.last_records_enabled == keep_last, where          # travels with the state blob
             eng.set_illegal_move_reward(irw)
             eng.set_max_tile(max_tile)
         check_state(eng, ora, where, always_auto_reset=auto_reset)

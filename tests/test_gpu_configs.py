@@ -2,6 +2,7 @@
 
   configs[1]  65 536 boards, random policy          -> tests/test_gpu_parity.py::test_random_rollout_vs_oracle
   configs[2]  2^20 boards, random policy            -> test_full_batch_2p20_random_policy_vs_oracle (full batch)
+              + exactly as bench.py times it         -> test_bench_configuration_2p20_rollout_buffers_without_terminal_records
               + a legality-aware greedy policy (deep states: big tiles, full-board endings)
   configs[3]  shards of one batch on several ranks  -> test_two_rank_hip_shards_allgather (2 processes, gloo, cuda:0)
               + the N > 1 code path of bench.py over RCCL -> test_bench_forced_dist_runs_the_rccl_path (one-rank group)
@@ -46,6 +47,53 @@ def test_full_batch_2p20_random_policy_vs_oracle(torch_cuda):
     assert np.array_equal(eng.get_last_scores(), ora.last_score)
     st = eng.episode_stats()
     assert st["episodes"] == int(ora.ep_count.sum()) > n
+
+
+def test_bench_configuration_2p20_rollout_buffers_without_terminal_records(torch_cuda):
+    """The configuration bench.py times, at its real size: 2^20 boards, the STANDARD step kernel through g2048_rollout
+    over [K][B] uint8 action / float32 reward / uint8 terminated buffers, per-board terminal records OFF
+    (g2048_set_last_records(0)).  Every step's rewards and flags, the final boards and scores, the episode counters and
+    the exact return sum against the C oracle; the calls that need terminal records refuse; switching them on again
+    starts from "none yet" and from then on records exactly the episodes that end."""
+    torch = torch_cuda
+    from gym2048_amd._lib import G2048Error
+    from gym2048_amd.batched import Batched2048, parse_stats
+    from oracle import OracleBatch
+    n, seed, k = 1 << 20, 42, 24
+    eng, ora = Batched2048(n, seed=seed, last_records=False), OracleBatch(n, seed, threads=0)
+    assert not eng.last_records_enabled
+    eng.reset()
+    ora.reset()
+    acts = eng.random_actions(k)
+    rew = torch.zeros((k, n), dtype=torch.float32, device=eng.device)
+    term = torch.zeros((k, n), dtype=torch.uint8, device=eng.device)
+    eng.prepare_rollout(acts, reward=rew, terminated=term).run()
+    torch.cuda.synchronize()
+    for j in range(k):
+        ora.step(None)                                       # the synthetic policy = the generated actions
+        assert np.array_equal(rew[j].cpu().numpy(), ora.reward), j
+        assert np.array_equal(term[j].cpu().numpy(), ora.terminated), j
+    _compare_state(eng, ora, k)
+    st = eng.episode_stats()
+    assert st["episodes"] == int(ora.ep_count.sum()) > n // 2
+    assert st["return_sum"] == ora.return_sum == ora.finished_return_sum > 0
+    assert st["last_count"] == st["last_score_sum"] == st["last_score_max"] == 0       # not kept
+    ro = parse_stats(eng.episode_stats_device(returns_only=True))
+    assert (ro["episodes"], ro["illegal_ends"], ro["return_sum"]) == (st["episodes"], st["illegal_ends"], st["return_sum"])
+    for call in (eng.get_last_scores, eng.last_scores, eng.last_records):
+        with pytest.raises(G2048Error, match="terminal records"):
+            call()
+    eng.set_last_records(True)
+    assert eng.last_records_enabled and not eng.get_last_scores().any()
+    ended = np.zeros(n, bool)
+    for _ in range(6):
+        eng.step(None)
+        ora.step(None)
+        ended |= ora.terminated.astype(bool)
+    got = eng.get_last_scores()
+    assert np.array_equal(got[ended], ora.last_score[ended]) and not got[~ended].any()
+    _compare_state(eng, ora, k + 6)
+    assert eng.episode_stats()["return_sum"] == ora.return_sum
 
 
 def _greedy_actions(torch, eng):
