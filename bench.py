@@ -598,7 +598,6 @@ def main():
         # (b1) BASELINE configs[4]: the env driven by a ppo_train.py-shaped policy on the same GPU (bench_policy.py)
         try:
             import bench_policy
-            os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # no exhaustive convolution search on a fresh box
             extras["policy_loop"] = bench_policy.run(boards=B, steps=10, warmup=2)
         except Exception as exc:  # pragma: no cover
             extras["policy_loop"] = {"error": str(exc)}

@@ -506,6 +506,7 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
 
 // ------------------------------------------------------------------------- fused rollout
 // k steps of the synthetic random policy in ONE launch; the record never leaves registers.
+constexpr uint32_t kGainFold = 1024;
 __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p)
 {
     __shared__ WaveTables s_tables[kBlock / 64];
@@ -517,15 +518,22 @@ __global__ void __launch_bounds__(kBlock) rollout_random_kernel(const StepArgs p
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of the first step
     uint32_t episodes = 0, illegal_ends = 0;
-    unsigned long long gained = 0; // this lane's merge scores over the k steps (reduced over the wave once, at the end)
-    for (uint32_t j = 0; j < p.k_steps; ++j, ++t) {
-        const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
-                                      p.seed_lo, p.seed_hi);
-        const StepOut o = play_record(rec, w.w[3] >> 30, w, p.max_exp, tb);
-        gained += o.gain;
-        record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
-        if (o.terminated)
-            reset_record(rec, o, w, tb);
+    // this lane's merge scores over the k steps (reduced over the wave once, at the end): one 32-bit add per step, folded
+    // into 64 bits every kGainFold steps (a move gains less than the sum of the tiles, < 2^22: 1 024 of them fit 32 bits)
+    unsigned long long gained = 0;
+    for (uint32_t j0 = 0; j0 < p.k_steps; j0 += kGainFold) {
+        const uint32_t j1 = p.k_steps - j0 < kGainFold ? p.k_steps : j0 + kGainFold;
+        uint32_t gained32 = 0;
+        for (uint32_t j = j0; j < j1; ++j, ++t) {
+            const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
+                                          p.seed_lo, p.seed_hi);
+            const StepOut o = play_record(rec, w.w[3] >> 30, w, p.max_exp, tb);
+            gained32 += o.gain;
+            record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
+            if (o.terminated)
+                reset_record(rec, o, w, tb);
+        }
+        gained += gained32;
     }
     if (valid)
         store_board(p.st.boards, i, rec);
@@ -590,7 +598,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint64_t t = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo;
     uint32_t episodes = 0, illegal_ends = 0;
-    unsigned long long gained = 0; // this lane's merge scores over the k steps
+    unsigned long long gained = 0; // this lane's merge scores over the k steps: 32-bit adds, folded once per double group
+    uint32_t gained32 = 0;
     unsigned long long ended_last = 0; // lanes whose episode the LAST step ended (pending marks when auto_reset == 0)
     // step j with its action; t advances with it
     auto one_step = [&](uint32_t j, uint32_t action_in) {
@@ -600,7 +609,7 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
         ++t;
         const uint32_t action = ACT == 0 ? w.w[3] >> 30 : action_in & 3u;
         const StepOut o = play_record(rec, action, w, p.max_exp, tb);
-        gained += o.gain;
+        gained32 += o.gain;
         ended_last = record_episode_ends(p, i, o.terminated && valid, !o.legal, rec, episodes, illegal_ends);
         if (valid) {
             if (reward)
@@ -633,6 +642,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
                 ahead[q] = fetch(j0 + q + 2u * kPrefetch);
             one_step(j0 + kPrefetch + q, static_cast<uint32_t>(set_b[q]));
         }
+        gained += gained32;
+        gained32 = 0;
     }
     // the last k % (2 * kPrefetch) steps: the first kPrefetch of them have their actions in flight already
 #pragma unroll
@@ -641,6 +652,7 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
             one_step(j0 + q, static_cast<uint32_t>(ahead[q]));
     for (uint32_t j = j0 + kPrefetch; j < k; ++j)
         one_step(j, static_cast<uint32_t>(fetch(j)));
+    gained += gained32; // (at most 2 * kPrefetch - 1 tail steps)
     if (valid)
         store_board_nt(p.st.boards, i, rec);
     flush_episode_counts(counters, episodes, illegal_ends, wave_sum64_lane63(valid ? gained : 0ull),

@@ -157,8 +157,8 @@ def test_stream_signal_wait_and_capture_refusal(torch_cuda):
     for rep in range(3):
         eng.rollout(acts if rep == 0 else k, reward=rew)
         tickets.append(eng.stream_signal())
-        eng.stream_wait(tickets[-1])
-        assert torch.cuda.current_stream(eng.device).query()          # nothing left on the stream when the word arrived
+        eng.stream_wait(tickets[-1])       # (the stream itself may still report "busy" for a moment: the word is
+                                           #  published by the signal kernel's store, its retirement follows)
         for _ in range(k):
             ora.step(None)
         assert np.array_equal(rew[-1].cpu().numpy(), ora.reward)
