@@ -337,7 +337,7 @@ def main():
     # ---- device warm-up on a scratch engine (every rank): not steps of the benchmarked engine, whose own
     #      warm-up is exactly the W steps below
     if args.device_warmup > 0:
-        scratch = Batched2048(B, device=local_rank, seed=SEED + 1)
+        scratch = Batched2048(B, device=local_rank, seed=SEED + 1, last_records=keep_last)     # same kernel configuration
         scratch.reset()
         sa = scratch.random_actions(32)
         sr = torch.zeros((32, B), dtype=torch.float32, device=dev)
@@ -564,7 +564,7 @@ def main():
         del reward, terminated, actions
         try:
             nb, kb = 1 << 24, 24
-            big = Batched2048(nb, device=local_rank, seed=SEED)
+            big = Batched2048(nb, device=local_rank, seed=SEED, last_records=keep_last)   # as the headline engine
             big.reset()
             big.rollout_random(AGE_STEPS)
             ab = big.random_actions(kb)
