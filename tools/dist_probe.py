@@ -25,7 +25,7 @@ actions = eng.random_actions(K)
 reward = torch.zeros((K, B), dtype=torch.float32, device=dev)
 term = torch.zeros((K, B), dtype=torch.uint8, device=dev)
 plan = eng.prepare_rollout(actions, reward=reward, terminated=term)
-stats_buf = torch.empty(168, dtype=torch.uint8, device=dev)
+stats_buf = torch.empty(176, dtype=torch.uint8, device=dev)   # sizeof(g2048_stats)
 ret_buf = torch.empty(B, dtype=torch.int32, device=dev)
 shard = weak_shard(B, 0, 1)
 for _ in range(30):
@@ -68,9 +68,9 @@ dist.barrier()
 show("one-rank RCCL group, no barrier: 20 launches", region(nothing, nothing))
 show("one-rank RCCL group: barrier | 20 launches", region(dist.barrier, nothing))
 show("one-rank RCCL group: barrier | 20 launches + summary kernels", region(dist.barrier, lambda: eng.episode_stats_device(out=stats_buf, returns_only=True)))
-show("one-rank RCCL group: barrier | 20 launches + summary kernels + all-gather(168 B)",
+show("one-rank RCCL group: barrier | 20 launches + summary kernels + all-gather(176 B)",
      region(dist.barrier, lambda: allgather_stats(eng.episode_stats_device(out=stats_buf, returns_only=True))))
-show("one-rank RCCL group: barrier | 20 launches + all-gather(168 B) of a stale buffer", region(dist.barrier, lambda: allgather_stats(stats_buf)))
+show("one-rank RCCL group: barrier | 20 launches + all-gather(176 B) of a stale buffer", region(dist.barrier, lambda: allgather_stats(stats_buf)))
 show("one-rank RCCL group: barrier | 20 launches + export + all-gather(int32[B])",
      region(dist.barrier, lambda: allgather_returns(eng.last_scores(out=ret_buf), shard)))
 dist.destroy_process_group()

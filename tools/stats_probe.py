@@ -12,7 +12,7 @@ for lg in (20, 16, 24):
     for _ in range(20): d = e.episode_stats_device()
     ev1.record(); torch.cuda.synchronize()
     print(f"2^{lg}: episode_stats_device {ev0.elapsed_time(ev1) * 1e3 / 20:.1f} us per call", e.episode_stats()["episodes"])
-    buf = torch.empty(168, dtype=torch.uint8, device=e.device)
+    buf = torch.empty(176, dtype=torch.uint8, device=e.device)   # sizeof(g2048_stats)
     for _ in range(3): e.episode_stats_device(out=buf, returns_only=True)
     ev0.record()
     for _ in range(20): e.episode_stats_device(out=buf, returns_only=True)
