@@ -216,6 +216,60 @@ def test_return_sum_accounting_through_every_call_that_moves_a_score(torch_cuda,
     assert st["mean_episode_return"] == (st["return_sum"] - st["illegal_ends"]) / st["episodes"]     # illegal_move_reward = -1
 
 
+def test_episode_slot_carries_into_the_high_dwords(torch_cuda):
+    """A launch stores only the LOW dwords of its wavefront's episode slot; the high halves follow on a carry, once in
+    2^32 counts -- a path no ordinary test reaches.  Here the slots of a checkpoint are patched to sit a few counts
+    below 2^32 (episodes, illegal ends and the gain total G), loaded back, and the next steps must carry: the statistics
+    move by exactly what the oracle counts from there on.  Also: a fused random rollout longer than the 1 024-step fold of
+    its per-lane 32-bit gain accumulator."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed = 4096, 31
+    eng, ora = Batched2048(n, seed=seed), OracleBatch(n, seed)
+    eng.reset()
+    ora.reset()
+    for _ in range(20):
+        eng.step(None)
+        ora.step(None)
+    st0 = eng.episode_stats()
+    assert st0["return_sum"] == ora.finished_return_sum and st0["episodes"] == int(ora.ep_count.sum())
+    state = eng.state_dict()
+    blob = state["blob"].copy()
+    header, up = 56, lambda x: (x + 255) & ~255             # StateHeader; slab = records | terminal records | slots | stats
+    slots = blob[header + 2 * up(n * 16): header + 2 * up(n * 16) + (n // 64) * 32].view(np.uint32).reshape(n // 64, 8)
+    old = slots.astype(np.int64)
+    assert not slots[:, 4:7].any()                           # nothing has carried yet
+    near = np.uint32(0xFFFFFFF0)
+    slots[:, 0:3] = near                                     # episodes.lo, illegal_ends.lo, G.lo of every wavefront
+    shift = ((int(near) - old[:, 0]).sum(), (int(near) - old[:, 1]).sum(), (int(near) - old[:, 2]).sum())
+    eng.load_state_dict(dict(state, blob=blob))
+    st1 = eng.episode_stats()
+    assert st1["episodes"] == st0["episodes"] + shift[0] and st1["illegal_ends"] == st0["illegal_ends"] + shift[1]
+    assert st1["return_sum"] == st0["return_sum"] + shift[2]
+    ep0, ret0, ill0 = int(ora.ep_count.sum()), ora.finished_return_sum, 0
+    for s in range(30):                                      # every wavefront passes 2^32 in all three counters
+        eng.step(None)
+        ora.step(None)
+        ill0 += int((ora.illegal.astype(bool) & ora.terminated.astype(bool)).sum())
+    st2 = eng.episode_stats()
+    assert st2["episodes"] - st1["episodes"] == int(ora.ep_count.sum()) - ep0 > 64 * 30 // 20
+    assert st2["illegal_ends"] - st1["illegal_ends"] == ill0
+    assert st2["return_sum"] - st1["return_sum"] == ora.finished_return_sum - ret0 > 0
+    raw = eng.state_dict()["blob"][header + 2 * up(n * 16): header + 2 * up(n * 16) + (n // 64) * 32].view(np.uint32).reshape(-1, 8)
+    assert (raw[:, 4] == 1).all() and (raw[:, 6] == 1).all() and (raw[:, 5] == 1).all()      # carried, once
+    # ---- a fused rollout across the accumulator fold
+    eng2, ora2 = Batched2048(512, seed=seed), OracleBatch(512, seed)
+    eng2.reset()
+    ora2.reset()
+    eng2.rollout_random(2500)
+    for _ in range(2500):
+        ora2.step(None)
+    st = eng2.episode_stats()
+    assert st["return_sum"] == ora2.finished_return_sum == ora2.return_sum and st["episodes"] == int(ora2.ep_count.sum())
+    assert np.array_equal(eng2.get_boards().reshape(512, 16), ora2.boards) and np.array_equal(eng2.get_scores(), ora2.score)
+
+
 def test_rollout_writes_terminal_boards(torch_cuda):
     """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
     episode and holds the board the episode ended on."""
