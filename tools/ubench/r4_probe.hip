@@ -7,7 +7,8 @@
 //   r4-noterm the product step without the sparse 16-byte terminal-record store (what per-board last returns cost)
 // (A variant with the gain sum as one ds_add_u32 per lane to a zeroed LDS word measured 10.60 us against 10.36 for the
 // DPP form at 2^20 boards and its sums did not cross-check: dropped, profiles/r04_b_r4_probe_2p20.txt.)
-// Usage: r4_probe [log2_boards] [rounds] [launches]
+//   r4-noterm + touch ...: first-generation wavefronts pull the next generation's records into their XCD's L2
+// Usage: r4_probe [log2_boards] [rounds] [launches] [touch distance in boards = 2048 * 256]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -45,6 +46,17 @@ probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, 
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     Board rec = load_board_nt(p.st.boards, i);
     const uint2 tables_piece = load_tables_piece();
+    // MODE 4 / 5: a first-generation wavefront touches the records (MODE 5: and the actions) of the block that will run in
+    // its wave slots NEXT (same XCD: block + 8 * 256 slots-per-XCD), so that they sit in that XCD's L2 when it starts
+    uint32_t touched = 0;
+    if constexpr (MODE >= 4) {
+        const uint32_t partner = i + tail.max_exp; // (max_exp is unused in this probe: carries the prefetch distance in boards)
+        if (partner < n) {
+            touched = reinterpret_cast<const uint32_t *>(p.st.boards + partner)[0];
+            if constexpr (MODE == 5)
+                touched ^= static_cast<const uint8_t *>(p.actions)[partner];
+        }
+    }
     const EpisodeCounters counters = load_episode_counters(p, i);
     const Words w = philox4x32_10(t_lo, t_hi, board_offset + i, 0u, seed_lo, seed_hi);
     const uint32_t action = load_action<1>(p.actions, i, w.w[3]);
@@ -52,7 +64,7 @@ probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, 
     const StepOut o = play_record(rec, action, w, 0u, tb);
     uint32_t episodes = 0, illegal_ends = 0;
     unsigned long long done;
-    if constexpr (MODE == 3) {
+    if constexpr (MODE >= 3) {
         done = __builtin_amdgcn_ballot_w64(o.terminated);
         episodes = static_cast<uint32_t>(__popcll(done));
         illegal_ends = static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(o.terminated && !o.legal)));
@@ -69,6 +81,8 @@ probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, 
     __builtin_nontemporal_store(o.legal ? static_cast<float>(o.gain) : tail.illegal_reward, p.reward + i);
     __builtin_nontemporal_store(static_cast<uint8_t>(o.terminated ? 1 : 0), p.terminated + i);
     flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending);
+    if constexpr (MODE >= 4)
+        asm volatile("" ::"v"(touched)); // the touch is consumed here, after everything else
 }
 
 struct Variant { std::string name; std::function<void(uint32_t j, hipStream_t s)> launch; };
@@ -85,7 +99,7 @@ int main(int argc, char **argv)
         CHECK(hipMalloc(&boards, (size_t)n * 16)); CHECK(hipMalloc(&last, (size_t)n * 16)); CHECK(hipMalloc(&ctr, (size_t)(n / 64 + 16) * 32));
         CHECK(hipMemset(boards, 0, (size_t)n * 16)); CHECK(hipMemset(last, 0, (size_t)n * 16)); CHECK(hipMemset(ctr, 0, (size_t)(n / 64 + 16) * 32));
     };
-    const int NV = 4;
+    const int NV = 6;
     uint4 *boards[NV], *last[NV]; unsigned long long *ctr[NV];
     for (int v = 0; v < NV; ++v) state(boards[v], last[v], ctr[v]);
     uint8_t *actions, *term; float *reward;
@@ -115,6 +129,12 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((step_kernel<1, true, true, false>), g, b, 0, st, boards[1], (const void *)(actions + (size_t)(j % R) * n), ctr[1], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(1, j)); }});
     vs.push_back({"r4-noterm (no terminal-record store)", [&](uint32_t j, hipStream_t st) {
         hipLaunchKernelGGL((probe_step<3>), g, b, 0, st, boards[2], (const void *)(actions + (size_t)(j % R) * n), ctr[2], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(2, j)); }});
+    auto tail_pf = [&](int v, uint32_t j, uint32_t dist) { StepTail t = tail_of(v, j); t.max_exp = dist; return t; };
+    const uint32_t dist = argc > 4 ? (uint32_t)atoi(argv[4]) : 2048u * 256u; // boards between a block and the one that follows it in its wave slots
+    vs.push_back({"r4-noterm + touch next block's records", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<4>), g, b, 0, st, boards[4], (const void *)(actions + (size_t)(j % R) * n), ctr[4], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_pf(4, j, dist)); }});
+    vs.push_back({"r4-noterm + touch records and actions", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<5>), g, b, 0, st, boards[5], (const void *)(actions + (size_t)(j % R) * n), ctr[5], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_pf(5, j, dist)); }});
     vs.push_back({"r4-nosum (slot, no gain sum)", [&](uint32_t j, hipStream_t st) {
         hipLaunchKernelGGL((probe_step<0>), g, b, 0, st, boards[3], (const void *)(actions + (size_t)(j % R) * n), ctr[3], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(3, j)); }});
     hipEvent_t e0, e1;
