@@ -7,6 +7,18 @@ cd "$(dirname "$0")/.."
 S=gpurun_out/prof_$T
 cp $S/summary.txt profiles/${T}_rocprofv3_summary.txt
 cp $S/kernel_stats.csv profiles/${T}_kernel_stats.csv
+# stamp the traffic file with the kernel-trace average of the same run (what bench.py prints as roofline.profiled_launch_us)
+python - "$S" <<'PY'
+import csv, json, sys
+s = sys.argv[1]
+t = json.load(open(f"{s}/traffic.json"))
+for row in csv.DictReader(open(f"{s}/kernel_stats.csv")):
+    if "step_kernel<1, true, true, false>" in row["Name"]:
+        t["kernel_trace_avg_us"] = float(row["AverageNs"]) / 1e3
+        t["kernel_trace_dispatches"] = int(row["Calls"])
+        break
+json.dump(t, open(f"{s}/traffic.json", "w"), indent=1)
+PY
 cp $S/traffic.json profiles/${T}_traffic.json
 cp $S/traffic.json profiles/traffic_latest.json
 cp $S/bench_under_rocprof.json profiles/${T}_bench_under_rocprof.json
