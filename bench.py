@@ -338,28 +338,9 @@ def main():
         local = eng.episode_stats_device(out=stats_buf, returns_only=True)
         return allgather_stats(local.cpu() if host_gather else local)
 
-    # ---- device warm-up on a scratch engine (every rank): not steps of the benchmarked engine, whose own
-    #      warm-up is exactly the W steps below
-    if args.device_warmup > 0:
-        scratch = Batched2048(B, device=local_rank, seed=SEED + 1, last_records=keep_last)     # same kernel configuration
-        scratch.reset()
-        kw = 128                                         # launches per warm-up train (~1.2 ms): SUSTAINED streaming, as in the
-        sa = scratch.random_actions(kw)                  # long-running job the metric describes -- a launch is ~0.3 us slower
-        sr = torch.zeros((kw, B), dtype=torch.float32, device=dev)      # in the first ~20 launches after an idle gap
-        st_ = torch.zeros((kw, B), dtype=torch.uint8, device=dev)       # (profiles/r04_g_train_position.txt)
-        wplan = scratch.prepare_rollout(sa, reward=sr, terminated=st_)
-        scratch.rollout_random(128)                      # shader clocks
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < args.device_warmup:      # memory clocks: per-step launches that stream
-            wplan.run()
-            torch.cuda.synchronize()
-        scratch.close()
-        del wplan
-        del scratch, sa, sr, st_
-
-    # ---- inputs and outputs of the timed K steps: allocated, generated and TOUCHED before any timing
-    #      (a fresh box's first touch of a page must not land in the timed region), then the W untimed
-    #      warm-up steps, then -- with nothing in between -- the timed region
+    # ---- everything the timed region and its warm-up steps need is allocated, generated and TOUCHED first (a fresh
+    #      box's first touch of a page must not land in the timed region; allocations and frees idle or synchronise the
+    #      device for milliseconds), so that NOTHING but launches stands between the device warm-up and the timed region
     actions = eng.random_actions(K, t_first=eng.clock + 1 + W)   # [K][B] u8, resident in HBM
     reward = torch.zeros((K, B), dtype=torch.float32, device=dev)
     terminated = torch.zeros((K, B), dtype=torch.uint8, device=dev)
@@ -370,13 +351,37 @@ def main():
     close_by_poll = os.environ.get("G2048_BENCH_CLOSE", "poll") != "sync"
     if close_by_poll:
         eng.stream_wait(eng.stream_signal())             # first use allocates the completion word: not in the timed region
+    wplans = []
     if W > 0:
         wa = eng.random_actions(W)
         wr = torch.zeros((min(W, 8), B), dtype=torch.float32, device=dev)
         wt = torch.zeros((min(W, 8), B), dtype=torch.uint8, device=dev)
         for j0 in range(0, W, 8):                        # same kernel, same outputs as the timed steps
             kk = min(8, W - j0)
-            eng.rollout(wa[j0:j0 + kk], reward=wr[:kk], terminated=wt[:kk])
+            wplans.append(eng.prepare_rollout(wa[j0:j0 + kk], reward=wr[:kk], terminated=wt[:kk]))
+
+    # ---- device warm-up on a scratch engine (every rank): not steps of the benchmarked engine, whose own warm-up is
+    #      exactly the W steps below.  SUSTAINED 128-launch trains of the same kernel in the same configuration: shader
+    #      and memory clocks at the level of the long-running job the metric describes.  It runs LAST -- the device
+    #      loses that state within a few hundred microseconds of idling (tools/ubench/gap_probe.hip: a 20-launch train
+    #      takes 199.8 us right after a synchronize, 207.7 us after 0.5 ms of idle, 210.8 us after 2 ms) -- and the
+    #      scratch engine is only freed after the timed region (hipFree synchronises the device).
+    scratch = None
+    if args.device_warmup > 0:
+        scratch = Batched2048(B, device=local_rank, seed=SEED + 1, last_records=keep_last)     # same kernel configuration
+        scratch.reset()
+        kw = 128                                         # launches per warm-up train (~1.2 ms)
+        sa = scratch.random_actions(kw)
+        sr = torch.zeros((kw, B), dtype=torch.float32, device=dev)
+        st_ = torch.zeros((kw, B), dtype=torch.uint8, device=dev)
+        wplan = scratch.prepare_rollout(sa, reward=sr, terminated=st_)
+        scratch.rollout_random(128)                      # shader clocks
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.device_warmup:      # memory clocks: per-step launches that stream
+            wplan.run()
+            torch.cuda.synchronize()
+    for wp in wplans:                                    # the W untimed warm-up steps of the benchmarked engine
+        wp.run()
     barrier()                                            # opening bracket: barrier + synchronize
     ev0.record()                                         # on the (idle) launch stream: start of the launch train
     t0 = time.perf_counter()
@@ -400,6 +405,9 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         sync_after_us = 0.0
+    if scratch is not None:
+        scratch.close()
+        del scratch, sa, sr, st_, wplan
     kernel_region_ms = ev0.elapsed_time(ev1)
     collective_ms = ev1.elapsed_time(ev2) if dist_on else 0.0
 
