@@ -375,11 +375,17 @@ def main():
         sr = torch.zeros((kw, B), dtype=torch.float32, device=dev)
         st_ = torch.zeros((kw, B), dtype=torch.uint8, device=dev)
         wplan = scratch.prepare_rollout(sa, reward=sr, terminated=st_)
+        wshort = scratch.prepare_rollout(sa[:16], reward=sr[:16], terminated=st_[:16])
         scratch.rollout_random(128)                      # shader clocks
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < args.device_warmup:      # memory clocks: per-step launches that stream
-            wplan.run()
-            torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()                               # the ranks START the warm-up together, so that they also end it
+        t_end = time.perf_counter() + args.device_warmup  # together: a rank that waited for the others at the opening barrier
+        while True:                                      # for a millisecond would start the timed region cooled down
+            left = t_end - time.perf_counter()
+            if left <= 0:
+                break
+            (wplan if left > 4e-3 else wshort).run()     # memory clocks: per-step launches that stream; short trains at the
+            torch.cuda.synchronize()                     # end, so that every rank stops within ~0.2 ms of the deadline
     for wp in wplans:                                    # the W untimed warm-up steps of the benchmarked engine
         wp.run()
     barrier()                                            # opening bracket: barrier + synchronize
@@ -407,7 +413,7 @@ def main():
         sync_after_us = 0.0
     if scratch is not None:
         scratch.close()
-        del scratch, sa, sr, st_, wplan
+        del scratch, sa, sr, st_, wplan, wshort
     kernel_region_ms = ev0.elapsed_time(ev1)
     collective_ms = ev1.elapsed_time(ev2) if dist_on else 0.0
 
