@@ -44,7 +44,20 @@ probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, 
     p.n = n;
     p.auto_reset = tail.auto_reset;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    Board rec = load_board_nt(p.st.boards, i);
+    uint32_t dep = 0;
+    Words w_early{};
+    if constexpr (MODE == 6) { // odd blocks: the Philox block BEFORE the loads are issued (their requests leave ~0.7 us later)
+        if (blockIdx.x & 1u) {
+            w_early = philox4x32_10(t_lo, t_hi, board_offset + i, 0u, seed_lo, seed_hi);
+            dep = w_early.w[0] & 0u; // a data dependency the compiler cannot see through
+            asm volatile("" : "+v"(dep));
+        }
+    }
+    if constexpr (MODE == 7) {
+        if (blockIdx.x & 1u)
+            __builtin_amdgcn_s_sleep(16); // 16 * 64 cycles ~ 0.43 us
+    }
+    Board rec = load_board_nt(p.st.boards, i + dep);
     const uint2 tables_piece = load_tables_piece();
     // MODE 4 / 5: a first-generation wavefront touches the records (MODE 5: and the actions) of the block that will run in
     // its wave slots NEXT (same XCD: block + 8 * 256 slots-per-XCD), so that they sit in that XCD's L2 when it starts
@@ -58,8 +71,12 @@ probe_step(uint4 *boards, const void *actions, unsigned long long *ep_counters, 
         }
     }
     const EpisodeCounters counters = load_episode_counters(p, i);
-    const Words w = philox4x32_10(t_lo, t_hi, board_offset + i, 0u, seed_lo, seed_hi);
-    const uint32_t action = load_action<1>(p.actions, i, w.w[3]);
+    Words w;
+    if (MODE == 6 && (blockIdx.x & 1u))
+        w = w_early;
+    else
+        w = philox4x32_10(t_lo, t_hi, board_offset + i, 0u, seed_lo, seed_hi);
+    const uint32_t action = load_action<1>(p.actions, i + dep, w.w[3]);
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
     const StepOut o = play_record(rec, action, w, 0u, tb);
     uint32_t episodes = 0, illegal_ends = 0;
@@ -99,7 +116,7 @@ int main(int argc, char **argv)
         CHECK(hipMalloc(&boards, (size_t)n * 16)); CHECK(hipMalloc(&last, (size_t)n * 16)); CHECK(hipMalloc(&ctr, (size_t)(n / 64 + 16) * 32));
         CHECK(hipMemset(boards, 0, (size_t)n * 16)); CHECK(hipMemset(last, 0, (size_t)n * 16)); CHECK(hipMemset(ctr, 0, (size_t)(n / 64 + 16) * 32));
     };
-    const int NV = 6;
+    const int NV = 8;
     uint4 *boards[NV], *last[NV]; unsigned long long *ctr[NV];
     for (int v = 0; v < NV; ++v) state(boards[v], last[v], ctr[v]);
     uint8_t *actions, *term; float *reward;
@@ -135,6 +152,10 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((probe_step<4>), g, b, 0, st, boards[4], (const void *)(actions + (size_t)(j % R) * n), ctr[4], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_pf(4, j, dist)); }});
     vs.push_back({"r4-noterm + touch records and actions", [&](uint32_t j, hipStream_t st) {
         hipLaunchKernelGGL((probe_step<5>), g, b, 0, st, boards[5], (const void *)(actions + (size_t)(j % R) * n), ctr[5], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_pf(5, j, dist)); }});
+    vs.push_back({"r4-noterm, odd blocks Philox before loads", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<6>), g, b, 0, st, boards[6], (const void *)(actions + (size_t)(j % R) * n), ctr[6], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(6, j)); }});
+    vs.push_back({"r4-noterm, odd blocks sleep 0.4 us first", [&](uint32_t j, hipStream_t st) {
+        hipLaunchKernelGGL((probe_step<7>), g, b, 0, st, boards[7], (const void *)(actions + (size_t)(j % R) * n), ctr[7], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(7, j)); }});
     vs.push_back({"r4-nosum (slot, no gain sum)", [&](uint32_t j, hipStream_t st) {
         hipLaunchKernelGGL((probe_step<0>), g, b, 0, st, boards[3], (const void *)(actions + (size_t)(j % R) * n), ctr[3], 0u, 42u, 0u, 100u + j, 0u, n, reward + (size_t)(j % R) * n, tail_of(3, j)); }});
     hipEvent_t e0, e1;
