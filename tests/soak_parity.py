@@ -47,9 +47,11 @@ for s in range(steps):
         assert np.array_equal(eng.get_scores(), ora.score), s
         assert np.array_equal(eng.get_last_scores(), ora.last_score), s
         assert np.array_equal(eng.highest.cpu().numpy(), ora.highest), s
+        assert eng.episode_stats()["return_sum"] == ora.finished_return_sum == ora.return_sum, s     # exact, all episodes
         assert np.array_equal(obs.cpu().numpy(), ora.onehot().astype(obs.cpu().numpy().dtype)), s   # fused observation
 st = eng.episode_stats()
 assert st["episodes"] == int(ora.ep_count.sum())
 print(f"soak ok: 2^{lg} boards x {steps} steps bit-exact vs oracle in {time.time() - t0:.0f} s; episodes {st['episodes']}, "
+      f"return sum {st['return_sum']} (mean episode score {st['mean_episode_score']:.1f}), "
       f"max tile 2^{st['max_exp']}, best last score {st['last_score_max']}, illegal ends {st['illegal_ends']}, "
       f"highest-tile histogram {[c for c in st['highest_hist'] if c]}")
