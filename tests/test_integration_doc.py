@@ -32,6 +32,9 @@ def test_integration_md_stub_runs_and_matches_engine(torch_cuda):
         eng.step(a)
         assert torch.equal(obs, eng.observe_onehot(torch.uint8))
         assert torch.equal(reward, eng.reward) and torch.equal(terminated, eng.terminated)
+    mean, episodes = stub.mean_episode_return()
+    st = eng.episode_stats()
+    assert episodes == st["episodes"] > 0 and mean == st["mean_episode_return"] == st["return_sum"] / st["episodes"]
 
 
 def test_integration_md_mentions_every_public_entry_point_group():
