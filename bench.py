@@ -3,10 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B]
 
-A "step" is one pass of the hot path over the whole batch: ONE launch of step_kernel per rank that
-advances every board by one action (move + score + spawn + done + auto-reset), reading the action
-from, and writing reward/terminated to, [K][B] rollout buffers that are resident in HBM before the
-timed region starts.  Workload = BASELINE configs[2]: B = 2^20 boards per GPU, synthetic uniform
+A "step" is one pass of the hot path over the whole batch: step_kernel advances every board by one action
+(move + score + spawn + done + auto-reset), reading the action from, and writing reward/terminated to, [K][B]
+rollout buffers that are resident in HBM before the timed region starts.  With --chains 2 (default) the pass is TWO
+launches per rank, one per half of the batch, run as two chains on two streams from two host threads
+(g2048_set_chains: bit-identical to one chain; the head of one half-batch kernel overlaps the tail of the other's);
+with --chains 1 it is ONE launch on one stream.  Workload = BASELINE configs[2]: B = 2^20 boards per GPU, synthetic uniform
 random policy (actions pre-generated on the device by g2048_fill_random_actions), seed 42.
 
 N > 1, one rank per GPU: either under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
@@ -62,6 +64,10 @@ def parse_args():
     ap.add_argument("--device-warmup", type=float, default=0.25,
                     help="seconds of GPU work on a SCRATCH engine before anything is measured (clocks at their "
                          "sustained level, as in a long-running job); 0 disables")
+    ap.add_argument("--chains", type=int, choices=[1, 2], default=2,
+                    help="launch chains per rollout (g2048_set_chains): 2 = the batch is cut in two and the halves run as two "
+                         "chains of launches on two streams from two host threads (bit-identical results; the head of one "
+                         "half-batch kernel overlaps the tail of the other's), 1 = one launch per step on one stream")
     ap.add_argument("--gather", choices=["summary", "full"], default="summary",
                     help="N > 1: what the once-per-rollout all-gather ships -- the per-rank return summary "
                          "(g2048_stats) or every board's last episodic return (int32[B])")
@@ -303,7 +309,7 @@ def main():
     # off (g2048_set_last_records: one sparse 16-byte store per finished episode less; extras.with_last_records has the
     # same launch train with them on); --gather full ships every board's last return and keeps them.
     keep_last = args.gather == "full"
-    eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset, last_records=keep_last)
+    eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset, last_records=keep_last, chains=args.chains)
     eng.reset()
     # State preparation (not timed, not counted as warm-up steps): SURVEY 8d defines the workload as ">= 1 000 steps
     # after >= 50 warm-up steps".  Right after a reset every board is two tiles old and a random move is illegal far
@@ -368,7 +374,7 @@ def main():
     #      scratch engine is only freed after the timed region (hipFree synchronises the device).
     scratch = None
     if args.device_warmup > 0:
-        scratch = Batched2048(B, device=local_rank, seed=SEED + 1, last_records=keep_last)     # same kernel configuration
+        scratch = Batched2048(B, device=local_rank, seed=SEED + 1, last_records=keep_last, chains=args.chains)   # same configuration
         scratch.reset()
         kw = 128                                         # launches per warm-up train (~1.2 ms)
         sa = scratch.random_actions(kw)
@@ -444,8 +450,12 @@ def main():
                             f"warm-up steps), then the W warm-up steps",
                    "device_warmup": (f"{args.device_warmup} s of rollouts on a SCRATCH engine (fused + per-step launches) "
                                      f"before anything is measured") if args.device_warmup > 0 else "none",
-                   "path": "one step_kernel launch per env-step (g2048_rollout), actions/reward/terminated in "
-                           "[K][B] HBM rollout buffers, auto-reset fused",
+                   "path": (("TWO step_kernel launches per env-step, one per half of the batch, as two chains on two streams "
+                             "issued by two host threads (g2048_set_chains(2): fork / join on the launch stream inside "
+                             "g2048_rollout; bit-identical to one chain), " if eng.chains == 2 else
+                             "one step_kernel launch per env-step (g2048_rollout), ") +
+                            "actions/reward/terminated in [K][B] HBM rollout buffers, auto-reset fused"),
+                   "chains": eng.chains,
                    "episode_bookkeeping": ("per-wavefront counters + exact return sum (g2048_stats.return_sum); per-board "
                                            "terminal records " + ("ON (--gather full reads them)" if keep_last else
                                                                   "OFF (g2048_set_last_records(0): not needed by the summary exchange; "
@@ -458,6 +468,14 @@ def main():
                      "traffic": traffic, "traffic_provenance": traffic_prov,
                      "kernel": "g2048::step_kernel<1, true, true, false>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us,
+                     "launches_per_step": eng.chains,
+                     "launch_us_note": ("time per ENV-STEP of the whole batch = HIP-event time of the region / K: with two chains "
+                                        "a step is two half-batch launches (2^19 boards each at the default size) that run "
+                                        "CONCURRENTLY on two streams, so a kernel trace shows half-batch kernels whose individual "
+                                        "durations (~7-8 us) overlap; `achieved` is the algorithmic bytes of a whole step over the "
+                                        "step time.  extras.single_chain is the one-launch-per-step form of the same engine "
+                                        "(its launch time IS a kernel duration: compare that one with profiles/*kernel_stats.csv)")
+                                       if eng.chains == 2 else "HIP-event time of the region / K = one kernel per step",
                      "issue_bound_note": "the step kernel saturates integer VALU issue before it saturates HBM: a compute-only "
                                          "copy of it takes 105.9 us of a 114.6-117.7 us launch at 2^24 boards and 7.8 of 10.2 us "
                                          "at 2^20, a memory-only copy 105.2 / 7.65 us (tools/ubench/r3_probe.hip part A, "
@@ -527,10 +545,35 @@ def main():
             del fa, fr, ft, fplan
         except Exception as exc:  # pragma: no cover
             extras["fused_rollout_with_io_steps_per_s"] = f"error: {exc}"
+        # (a2a) the same engine run as ONE chain (one whole-batch launch per step): the kernel-level figure that a
+        #       rocprofv3 kernel trace of `bench.py --chains 1` shows (profiles/*_kernel_stats.csv)
+        if eng.chains == 2:
+            try:
+                eng.set_chains(1)
+                kk = min(K, 200)
+                splan = eng.prepare_rollout(actions[:kk], reward=reward[:kk], terminated=terminated[:kk])
+                splan.run()
+                best = None
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    splan.run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3 / kk
+                    best = us if best is None else min(best, us)
+                extras["single_chain"] = {"launch_us": best, "steps_per_s": B / (best * 1e-6), "launches": kk,
+                                          "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * B / (best * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                del splan
+            except Exception as exc:  # pragma: no cover
+                extras["single_chain"] = {"error": str(exc)}
+            finally:
+                eng.set_chains(2)
         # (a2b) the timed launch train on an engine that KEEPS the per-board terminal records (the library's default):
         #       what g2048_get_last_scores / --gather full cost the step
         try:
-            other = Batched2048(B, device=local_rank, seed=SEED, last_records=not keep_last)
+            other = Batched2048(B, device=local_rank, seed=SEED, last_records=not keep_last, chains=args.chains)
             other.reset()
             other.rollout_random(AGE_STEPS)
             kk = min(K, 100)
@@ -585,7 +628,7 @@ def main():
         del reward, terminated, actions
         try:
             nb, kb = 1 << 24, 24
-            big = Batched2048(nb, device=local_rank, seed=SEED, last_records=keep_last)   # as the headline engine
+            big = Batched2048(nb, device=local_rank, seed=SEED, last_records=keep_last, chains=args.chains)   # as the headline engine
             big.reset()
             big.rollout_random(AGE_STEPS)
             ab = big.random_actions(kb)

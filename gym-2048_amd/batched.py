@@ -65,7 +65,8 @@ class Batched2048:
     """
 
     def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
-                 illegal_move_reward: float = 0.0, max_tile=None, rng: str = "philox", last_records: bool = True):
+                 illegal_move_reward: float = 0.0, max_tile=None, rng: str = "philox", last_records: bool = True,
+                 chains=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         if not torch.cuda.is_available():
@@ -95,6 +96,11 @@ class Batched2048:
         self._boards_view = None
         if not last_records:
             self.set_last_records(False)
+        # two-chain rollouts (g2048_set_chains): on by default where they pay -- half a million boards and more, spawn-stream mode
+        if chains is None:
+            chains = 2 if (self.n_envs >= (1 << 19) and rng == "philox") else 1
+        if chains != 1:
+            self.set_chains(chains)
         if self.rng_mode == "numpy":
             self.seed(seed)
 
@@ -136,6 +142,18 @@ class Batched2048:
         (-0.85 us per launch at 2^20 boards); ``last_scores`` / ``last_records`` / the ``last_*`` statistics then are
         unavailable, ``episodes`` / ``illegal_ends`` / the exact ``return_sum`` are not affected."""
         check(self._lib.g2048_set_last_records(self._h, int(bool(enable)), self._stream()))
+
+    def set_chains(self, chains: int):
+        """1: a rollout is one chain of launches on the current stream.  2: ``rollout`` cuts the batch in two and runs
+        the halves as two chains -- the lower half on the current stream from this thread, the upper half on an
+        engine-owned side stream from an engine-owned launch thread -- forked from and joined back into the current
+        stream inside every call; bit-identical results, 12-15 % less time per step at 2^19 .. 2^20 boards
+        (``g2048_set_chains``)."""
+        check(self._lib.g2048_set_chains(self._h, int(chains)))
+
+    @property
+    def chains(self) -> int:
+        return int(self._lib.g2048_get_chains(self._h))
 
     @property
     def last_records_enabled(self) -> bool:

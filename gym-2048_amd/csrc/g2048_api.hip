@@ -6,12 +6,15 @@
 
 #include <rccl/rccl.h> // declarations only: librccl is dlopen()ed by the first g2048_comm_* call
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -39,6 +42,86 @@ int fail(int code, const char *fmt, ...)
             return fail(G2048_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(err_));                       \
     } while (0)
 
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    _mm_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// The second launch thread of an engine that runs its rollouts as TWO CHAINS (g2048_set_chains): a rollout's launches
+// for the upper half of the batch are issued by this thread on the engine's side stream while the calling thread
+// issues the lower half's on the caller's stream.  One host thread issues a launch every ~3.3 us; fed by two threads,
+// both hardware queues always have a kernel waiting, and the head of one half-batch kernel (loads in flight, nothing
+// to compute yet) overlaps the tail of the other's (tools/ubench/overlap.hip: 9.4 -> 8.2 us per step at 2^20 boards).
+// The thread spins for a short while after a job (the next rollout of a training loop follows within microseconds) and
+// then sleeps on a condition variable.
+struct SideLauncher {
+    std::thread thread;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> posted{0}, finished{0};
+    std::atomic<bool> sleeping{false}, quit{false};
+    std::function<int()> job;
+    int result = 0;
+    char error[512] = "";
+
+    void run()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const auto idle_since = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (posted.load() == seen && !quit.load()) {
+                cpu_relax();
+                if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(500)) {
+                    std::unique_lock<std::mutex> lock(m);
+                    sleeping.store(true);
+                    cv.wait(lock, [&] { return posted.load() != seen || quit.load(); });
+                    sleeping.store(false);
+                }
+            }
+            if (quit.load())
+                return;
+            seen = posted.load();
+            result = job();
+            finished.store(seen);
+        }
+    }
+
+    uint64_t post(std::function<int()> fn)
+    {
+        job = std::move(fn);
+        const uint64_t ticket = posted.fetch_add(1) + 1;
+        if (sleeping.load()) {
+            std::lock_guard<std::mutex> lock(m);
+            cv.notify_one();
+        }
+        return ticket;
+    }
+
+    int wait(uint64_t ticket)
+    {
+        while (finished.load() < ticket)
+            cpu_relax();
+        return result;
+    }
+
+    void stop()
+    {
+        if (!thread.joinable())
+            return;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            quit.store(true);
+        }
+        cv.notify_one();
+        thread.join();
+    }
+};
+
 constexpr uint64_t kStateMagic = 0x3376383430324700ull; // "\0G2048v3": layout 3 = records carry the score, 4-word episode slots
 
 } // namespace
@@ -65,6 +148,11 @@ struct g2048_engine {
     // completion word (its own 64-byte pinned, device-mapped, coherent block): published by the device, polled by the host
     unsigned long long *done_host = nullptr, *done_dev = nullptr;
     unsigned long long done_count = 0;
+    // two-chain rollouts (g2048_set_chains): the side stream, its fork / join events and its launch thread
+    int chains = 1;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
+    SideLauncher *side = nullptr;
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
@@ -169,7 +257,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 11; }
+int g2048_abi_version(void) { return 12; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -237,8 +325,19 @@ int g2048_destroy(g2048_engine *e)
     if (!e)
         return G2048_OK;
     hipError_t err = hipSuccess;
+    if (e->side) {
+        e->side->stop();
+        delete e->side;
+        e->side = nullptr;
+    }
     if (e->slab) {
         (void)hipSetDevice(e->device);
+        if (e->side_stream)
+            (void)hipStreamDestroy(e->side_stream);
+        if (e->fork_event)
+            (void)hipEventDestroy(e->fork_event);
+        if (e->join_event)
+            (void)hipEventDestroy(e->join_event);
         if (e->st.rng)
             (void)hipFree(e->st.rng);
         if (e->scratch)
@@ -362,6 +461,74 @@ int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *s
     return G2048_OK;
 }
 
+// The buffers of step j of a rollout: the io pointers advanced by j * stride elements.
+static g2048_step_io io_of_step(const g2048_step_io &io, uint32_t j, uint64_t stride)
+{
+    g2048_step_io s = io;
+    const size_t off = static_cast<size_t>(j) * stride;
+    if (s.actions) s.actions = static_cast<const char *>(io.actions) + off * action_size(io.action_dtype);
+    if (s.reward) s.reward = io.reward + off;
+    if (s.terminated) s.terminated = io.terminated + off;
+    if (s.illegal) s.illegal = io.illegal + off;
+    if (s.highest) s.highest = io.highest + off;
+    if (s.terminal_boards) s.terminal_boards = io.terminal_boards + off * 16;
+    if (s.obs) s.obs = static_cast<char *>(io.obs) + off * obs_board_bytes(io.obs_dtype);
+    if (s.boards_out) s.boards_out = io.boards_out + off * 16;
+    return s;
+}
+
+// Launch arguments restricted to the boards [first, first + count) of the engine (first is a multiple of 256: whole
+// launch blocks and whole episode slots): every per-board pointer advanced by `first`, the global board index with it.
+static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t first, uint32_t count)
+{
+    a.st.boards += first;
+    if (a.st.last_record) a.st.last_record += first;
+    a.st.ep_counters += static_cast<size_t>(first / 64u) * g2048::kSlotWords;
+    if (a.actions) a.actions = static_cast<const char *>(a.actions) + static_cast<size_t>(first) * action_size(action_dtype);
+    if (a.reward) a.reward += first;
+    if (a.terminated) a.terminated += first;
+    if (a.illegal) a.illegal += first;
+    if (a.highest) a.highest += first;
+    if (a.terminal_boards) a.terminal_boards += first;
+    if (a.boards_out) a.boards_out += first;
+    if (a.obs) a.obs = static_cast<char *>(a.obs) + static_cast<size_t>(first) * obs_board_bytes(static_cast<int>(a.obs_dtype));
+    a.n = count;
+    a.board_offset += first;
+    return a;
+}
+
+static int ensure_side_chain(g2048_engine *e)
+{
+    if (e->side)
+        return G2048_OK;
+    G2048_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    G2048_HIP(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
+    G2048_HIP(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
+    SideLauncher *w = new (std::nothrow) SideLauncher;
+    if (!w)
+        return fail(G2048_ERR_NOMEM, "out of host memory");
+    w->thread = std::thread([w] { w->run(); });
+    e->side = w;
+    return G2048_OK;
+}
+
+int g2048_set_chains(g2048_engine *e, int chains)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (chains != 1 && chains != 2)
+        return fail(G2048_ERR_INVALID, "chains must be 1 or 2 (got %d)", chains);
+    if (chains == 2) {
+        G2048_HIP(hipSetDevice(e->device));
+        if (int rc = ensure_side_chain(e))
+            return rc;
+    }
+    e->chains = chains;
+    return G2048_OK;
+}
+
+int g2048_get_chains(const g2048_engine *e) { return e ? e->chains : 0; }
+
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream)
 {
@@ -370,29 +537,81 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     if (int rc = check_io(io))
         return rc;
     G2048_HIP(hipSetDevice(e->device));
-    const size_t asz = action_size(io->action_dtype);
-    for (uint32_t j = 0; j < k_steps; ++j) {
-        g2048_step_io s = *io;
-        const size_t off = static_cast<size_t>(j) * stride;
-        if (s.actions) s.actions = static_cast<const char *>(io->actions) + off * asz;
-        if (s.reward) s.reward = io->reward + off;
-        if (s.terminated) s.terminated = io->terminated + off;
-        if (s.illegal) s.illegal = io->illegal + off;
-        if (s.highest) s.highest = io->highest + off;
-        if (s.terminal_boards) s.terminal_boards = io->terminal_boards + off * 16;
-        if (s.obs) s.obs = static_cast<char *>(io->obs) + off * obs_board_bytes(io->obs_dtype);
-        if (s.boards_out) s.boards_out = io->boards_out + off * 16;
-        e->t += 1;
-        e->fresh = 0;
-        const g2048::StepArgs a = make_args(e, &s, auto_reset);
-        if (e->st.rng) {
-            G2048_HIP(g2048::launch_step_numpy(a, s.action_dtype, static_cast<hipStream_t>(stream)));
-            if (a.boards_out)
-                G2048_HIP(g2048::launch_export_boards(e->st.boards, a.n, a.boards_out, static_cast<hipStream_t>(stream)));
-        } else {
-            G2048_HIP(g2048::launch_step(a, s.action_dtype, static_cast<hipStream_t>(stream)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (k_steps == 0)
+        return G2048_OK;
+    // ---- two chains: the batch is cut at a block boundary and each half gets its own stream and launch thread.
+    //      Spawn-stream mode only (the numpy-RNG planes are indexed with the engine's board count), not while the
+    //      caller captures a graph (another thread must not launch during a global capture), and only when both halves
+    //      are whole blocks of work.
+    const uint32_t n = static_cast<uint32_t>(e->n);
+    const uint32_t first_half = (n / 2u) & ~255u;
+    bool two = e->chains == 2 && e->side && !e->st.rng && k_steps >= 2 && first_half >= 256u;
+    if (two) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+            (void)hipGetLastError();
+            two = false;
+        } else if (st != hipStreamCaptureStatusNone) {
+            two = false;
         }
     }
+    const uint64_t t0 = e->t;
+    e->t += k_steps;
+    e->fresh = 0;
+    auto args_of = [e, io, stride, auto_reset, t0](uint32_t j) {
+        const g2048_step_io sj = io_of_step(*io, j, stride);
+        g2048::StepArgs a = make_args(e, &sj, auto_reset);
+        const uint64_t t = t0 + 1u + j; // (make_args read e->t, which already stands at the end of the rollout)
+        a.t_lo = static_cast<uint32_t>(t);
+        a.t_hi = static_cast<uint32_t>(t >> 32);
+        return a;
+    };
+    if (!two) {
+        for (uint32_t j = 0; j < k_steps; ++j) {
+            const g2048::StepArgs a = args_of(j);
+            if (e->st.rng) {
+                G2048_HIP(g2048::launch_step_numpy(a, io->action_dtype, s));
+                if (a.boards_out)
+                    G2048_HIP(g2048::launch_export_boards(e->st.boards, a.n, a.boards_out, s));
+            } else {
+                G2048_HIP(g2048::launch_step(a, io->action_dtype, s));
+            }
+        }
+        return G2048_OK;
+    }
+    // fork: the side stream starts where the caller's stream stands
+    G2048_HIP(hipEventRecord(e->fork_event, s));
+    G2048_HIP(hipStreamWaitEvent(e->side_stream, e->fork_event, 0));
+    SideLauncher *w = e->side;
+    const int dtype = io->action_dtype;
+    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n]() -> int {
+        if (hipSetDevice(e->device) != hipSuccess)
+            return G2048_ERR_HIP;
+        for (uint32_t j = 0; j < k_steps; ++j) {
+            const hipError_t err = g2048::launch_step(part_of(args_of(j), dtype, first_half, n - first_half), dtype, e->side_stream);
+            if (err != hipSuccess) {
+                snprintf(w->error, sizeof w->error, "launch on the side chain failed at step %u: %s", j, hipGetErrorString(err));
+                return G2048_ERR_HIP;
+            }
+        }
+        const hipError_t err = hipEventRecord(e->join_event, e->side_stream);
+        if (err != hipSuccess) {
+            snprintf(w->error, sizeof w->error, "hipEventRecord on the side chain failed: %s", hipGetErrorString(err));
+            return G2048_ERR_HIP;
+        }
+        return G2048_OK;
+    });
+    hipError_t mine = hipSuccess;
+    for (uint32_t j = 0; j < k_steps && mine == hipSuccess; ++j)
+        mine = g2048::launch_step(part_of(args_of(j), dtype, 0u, first_half), dtype, s);
+    const int theirs = w->wait(ticket); // (the side thread has ISSUED its launches; nothing waits for the device here)
+    if (theirs != G2048_OK)
+        return fail(theirs, "%s", w->error);
+    // join: whatever the caller enqueues next runs after both halves
+    G2048_HIP(hipStreamWaitEvent(s, e->join_event, 0));
+    if (mine != hipSuccess)
+        return fail(G2048_ERR_HIP, "launch failed: %s", hipGetErrorString(mine));
     return G2048_OK;
 }
 
@@ -599,15 +818,6 @@ static int refuse_capture(hipStream_t s, const char *what)
     if (st != hipStreamCaptureStatusNone)
         return fail(G2048_ERR_INVALID, "%s blocks until the device has finished; it cannot be used on a capturing stream", what);
     return G2048_OK;
-}
-
-static inline void cpu_relax()
-{
-#if defined(__x86_64__)
-    _mm_pause();
-#else
-    std::this_thread::yield();
-#endif
 }
 
 static double wait_limit_seconds()

@@ -196,6 +196,19 @@ int g2048_stream_wait(g2048_engine *e, uint64_t ticket, void *stream);
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream);
 
+/* Two-chain rollouts.  With chains = 2, g2048_rollout cuts the batch in two at a block boundary and runs the halves as
+ * two independent chains of launches: the lower half on the caller's stream, issued by the calling thread, the upper
+ * half on an engine-owned side stream, issued by an engine-owned launch thread (created by this call).  Boards are
+ * independent (no cross-board state anywhere in game2048_env.py), so the results are bit-identical to chains = 1; what
+ * changes is that two hardware queues always have a kernel waiting, so the head of one half-batch kernel overlaps the
+ * tail of the other's: 9.4 -> 8.2 us per step at 2^20 boards, 5.6 -> 4.8 at 2^19, nothing below 2^19 or at 2^24
+ * (tools/ubench/overlap.hip).  The side stream is forked from and joined back into `stream` with events inside every
+ * g2048_rollout call, so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with
+ * k_steps >= 2 and at least 512 boards; everything else (g2048_step, numpy-RNG mode, a capturing stream) runs as one
+ * chain.  Default: 1. */
+int g2048_set_chains(g2048_engine *e, int chains);
+int g2048_get_chains(const g2048_engine *e);
+
 /* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /
  * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead
  * of 46).  For action sequences that are known in advance (replays, scripted or tree-search rollouts);

@@ -63,8 +63,9 @@ def one_case(case):
     if numpy_mode:
         n, seed, offset = min(n, 1500), seed % (1 << 40), offset % (1 << 20)
     keep_last = bool(rs.random() < 0.75)       # per-board terminal records on / off (g2048_set_last_records)
+    chains = int(rs.choice([1, 2]))            # rollouts as one chain or as two half-batch chains (g2048_set_chains)
     eng = Batched2048(n, seed=seed, board_offset=offset, illegal_move_reward=irw, max_tile=max_tile,
-                      rng="numpy" if numpy_mode else "philox", last_records=keep_last)
+                      rng="numpy" if numpy_mode else "philox", last_records=keep_last, chains=chains)
     ora = OracleBatch(n, seed, offset)
     ora.illegal_move_reward = irw
     ora.max_exp = 0 if max_tile is None else max_tile.bit_length() - 1
@@ -75,7 +76,7 @@ def one_case(case):
     ora.reset_numpy() if numpy_mode else ora.reset()
     dev = eng.device
     bump("numpy_mode_cases" if numpy_mode else "philox_cases")
-    tag = f"case {case}: n={n} seed={seed} offset={offset} irw={irw} max_tile={max_tile} auto_reset={auto_reset} numpy={numpy_mode}"
+    tag = f"case {case}: n={n} seed={seed} offset={offset} irw={irw} max_tile={max_tile} auto_reset={auto_reset} numpy={numpy_mode} chains={chains}"
     for call in range(int(rs.integers(12, 40))):
         kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state", "set_scores"],
                              p=[0.3, 0.18, 0.15, 0.08, 0.1, 0.06, 0.04, 0.06, 0.03]))
@@ -159,7 +160,7 @@ def one_case(case):
             ora.set_scores(sc)
         else:  # state save / restore into a fresh engine that then replaces the original
             blob = eng.state_dict()
-            other = Batched2048(n, seed=1, board_offset=0, rng="numpy" if numpy_mode else "philox")
+            other = Batched2048(n, seed=1, board_offset=0, rng="numpy" if numpy_mode else "philox", chains=chains)
             other.load_state_dict(blob)
             eng.close()
             eng = other

@@ -270,6 +270,76 @@ def test_episode_slot_carries_into_the_high_dwords(torch_cuda):
     assert np.array_equal(eng2.get_boards().reshape(512, 16), ora2.boards) and np.array_equal(eng2.get_scores(), ora2.score)
 
 
+@pytest.mark.parametrize("n", [512, 777, 5000, 65536 + 300])
+def test_two_chain_rollout_is_bit_identical(torch_cuda, n):
+    """g2048_set_chains(2): g2048_rollout cuts the batch at a block boundary and runs the halves as two chains of
+    launches (caller's stream / engine's side stream, two host threads).  Boards are independent, so EVERYTHING must be
+    bit-identical to one chain and to the oracle: every per-step output in [k, n] buffers (reward, terminated, illegal,
+    highest, terminal boards, plain boards, the fused observation), every action dtype, the state, the statistics and
+    the terminal records -- for batches whose second half is ragged, with work enqueued right before and right behind
+    the call on the caller's stream (fork / join), and interleaved with single-chain calls."""
+    torch = torch_cuda
+    from gym2048_amd import _lib
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    import ctypes as C
+    seed, k = 21, 9
+    two, one, ora = Batched2048(n, seed=seed, chains=2), Batched2048(n, seed=seed, chains=1), OracleBatch(n, seed)
+    assert two.chains == 2 and one.chains == 1
+    for e in (two, one, ora):
+        e.reset()
+    rs = np.random.default_rng(n)
+    dev = two.device
+
+    def buffers():
+        return dict(reward=torch.zeros((k, n), dtype=torch.float32, device=dev), terminated=torch.zeros((k, n), dtype=torch.uint8, device=dev),
+                    illegal=torch.zeros((k, n), dtype=torch.uint8, device=dev), highest=torch.zeros((k, n), dtype=torch.uint8, device=dev),
+                    terminal_boards=torch.zeros((k, n, 16), dtype=torch.uint8, device=dev),
+                    obs=torch.zeros((k, n, 16, 4, 4), dtype=torch.uint8, device=dev))
+
+    for rep, adt in enumerate((torch.uint8, torch.int32, torch.int64, None)):
+        acts = None if adt is None else torch.as_tensor(rs.integers(0, 4, (k, n))).to(dev).to(adt)
+        b2, b1 = buffers(), buffers()
+        bo2 = torch.zeros((k, n, 16), dtype=torch.uint8, device=dev)
+        for eng, b, bo in ((two, b2, bo2), (one, b1, None)):
+            a = eng.random_actions(k) if acts is None else acts
+            if bo is None:
+                eng.rollout(a, **b)
+            else:       # boards_out rides along through the raw ABI (the Python rollout has no argument for it)
+                io = eng._io(a, b["reward"], b["terminated"], b["illegal"], b["highest"], b["terminal_boards"], b["obs"])
+                io.boards_out = bo.data_ptr()
+                marker = torch.ones(1 << 20, device=dev).cumsum(0)        # work in flight on the caller's stream: the fork waits for it
+                _lib.check(eng._lib.g2048_rollout(eng._h, k, C.byref(io), n, 1, eng._stream()))
+                after = b["reward"].sum()                                   # enqueued behind the call: must see BOTH halves (join)
+        host_a = (one.random_actions(k, t_first=one.clock - k + 1) if acts is None else acts).cpu().numpy() & 3
+        total = 0.0
+        for j in range(k):
+            ora.step(host_a[j].astype(np.uint8))
+            total += float(ora.reward.sum())
+            for name in ("reward", "terminated", "illegal", "highest"):
+                want = getattr(ora, name)
+                assert np.array_equal(b2[name][j].cpu().numpy(), want), (name, rep, j)
+                assert np.array_equal(b1[name][j].cpu().numpy(), want), (name, rep, j)
+            done = ora.terminated.astype(bool)
+            assert np.array_equal(b2["terminal_boards"][j].cpu().numpy()[done], ora.terminal_boards[done]), (rep, j)
+            assert np.array_equal(b2["obs"][j].cpu().numpy(), ora.onehot()), (rep, j)
+            assert np.array_equal(bo2[j].cpu().numpy(), ora.boards), (rep, j)
+        assert float(after) == total
+        assert torch.equal(b2["obs"], b1["obs"]) and torch.equal(b2["terminal_boards"], b1["terminal_boards"])
+        for eng in (two, one):
+            assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards) and np.array_equal(eng.get_scores(), ora.score)
+            assert np.array_equal(eng.get_last_scores(), ora.last_score)
+        s2, s1 = two.episode_stats(), one.episode_stats()
+        assert s2 == s1 and s2["return_sum"] == ora.finished_return_sum and s2["episodes"] == int(ora.ep_count.sum())
+        assert two.clock == one.clock == ora.t
+        two.step(None)                                             # a single-chain call in between
+        one.step(None)
+        ora.step(None)
+    assert torch.equal(two.records(), one.records()) and torch.equal(two.last_records(), one.last_records())
+    two.close()
+    one.close()
+
+
 def test_rollout_writes_terminal_boards(torch_cuda):
     """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
     episode and holds the board the episode ended on."""

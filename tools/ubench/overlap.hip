@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <thread>
+#include <vector>
 
 #include "../../gym-2048_amd/csrc/g2048_kernels.hip"
 
@@ -63,6 +66,32 @@ int main(int argc, char **argv)
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("streams %d, boards 2^%d: %.2f us per step (events, incl. the final sync)\n", S, lg, ms * 1e3f / launches);
+    }
+    // ---- round 4: ONE HOST THREAD PER CHAIN (a single thread issues a launch every ~3.3 us, so S chains of
+    //      quarter-batch kernels were host-bound in round 2); wall clock from the first launch to the last chain's end
+    {
+        a.st.last_record = nullptr; // (round-4 bench configuration: no terminal records)
+        for (int q = 0; q < S; ++q) part[q].st.last_record = nullptr;
+        for (int rep = 0; rep < 5; ++rep) {
+            CHECK(hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            for (int q = 0; q < S; ++q)
+                th.emplace_back([&, q] {
+                    g2048::StepArgs p = part[q];
+                    for (int j = 0; j < launches; ++j) {
+                        p.t_lo = 100 + j;
+                        p.actions = actions + (size_t)j * n + (size_t)q * (n / S);
+                        p.reward = reward + (size_t)j * n + (size_t)q * (n / S);
+                        p.terminated = term + (size_t)j * n + (size_t)q * (n / S);
+                        (void)g2048::launch_step(p, 1, ss[q]);
+                    }
+                    (void)hipStreamSynchronize(ss[q]);
+                });
+            for (auto &t : th) t.join();
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            printf("%d chains, one host thread each, boards 2^%d: %.2f us per step (wall, incl. thread start and final syncs)\n", S, lg, us / launches);
+        }
     }
     // ---- the same S chains as ONE hipGraph (fork / join by events during capture): no per-launch host cost
     {
