@@ -440,6 +440,9 @@ def main():
     traffic, traffic_prov = traffic_for_current_sources(B)
     working_set_mib = (B * 16 * 2 + B * 6) / 2**20
 
+    # g2048_rollout runs as two chains only when the rollout is long enough for the overlap to build up (>= 48 steps,
+    # include/g2048.h g2048_set_chains); the driver's 20-step region is one chain either way
+    eff_chains = 2 if (eng.chains == 2 and K >= 48) else 1
     out = {
         "metric": ("env-steps/sec at batch=2^20 per MI355X" if B == (1 << 20) else f"env-steps/sec at batch={B} per MI355X"), "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -452,10 +455,12 @@ def main():
                                      f"before anything is measured") if args.device_warmup > 0 else "none",
                    "path": (("TWO step_kernel launches per env-step, one per half of the batch, as two chains on two streams "
                              "issued by two host threads (g2048_set_chains(2): fork / join on the launch stream inside "
-                             "g2048_rollout; bit-identical to one chain), " if eng.chains == 2 else
+                             "g2048_rollout; bit-identical to one chain), " if eff_chains == 2 else
                              "one step_kernel launch per env-step (g2048_rollout), ") +
                             "actions/reward/terminated in [K][B] HBM rollout buffers, auto-reset fused"),
-                   "chains": eng.chains,
+                   "chains": eff_chains,
+                   "chains_note": (f"engine set to {eng.chains} chains; rollouts shorter than 48 steps run as one chain (two chains "
+                                   f"need a few dozen steps to fill both hardware queues: profiles/r04_s_chains_by_k.txt)"),
                    "episode_bookkeeping": ("per-wavefront counters + exact return sum (g2048_stats.return_sum); per-board "
                                            "terminal records " + ("ON (--gather full reads them)" if keep_last else
                                                                   "OFF (g2048_set_last_records(0): not needed by the summary exchange; "
@@ -468,14 +473,14 @@ def main():
                      "traffic": traffic, "traffic_provenance": traffic_prov,
                      "kernel": "g2048::step_kernel<1, true, true, false>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                      "launch_us": launch_us,
-                     "launches_per_step": eng.chains,
+                     "launches_per_step": eff_chains,
                      "launch_us_note": ("time per ENV-STEP of the whole batch = HIP-event time of the region / K: with two chains "
                                         "a step is two half-batch launches (2^19 boards each at the default size) that run "
                                         "CONCURRENTLY on two streams, so a kernel trace shows half-batch kernels whose individual "
                                         "durations (~7-8 us) overlap; `achieved` is the algorithmic bytes of a whole step over the "
                                         "step time.  extras.single_chain is the one-launch-per-step form of the same engine "
                                         "(its launch time IS a kernel duration: compare that one with profiles/*kernel_stats.csv)")
-                                       if eng.chains == 2 else "HIP-event time of the region / K = one kernel per step",
+                                       if eff_chains == 2 else "HIP-event time of the region / K = one kernel per step",
                      "issue_bound_note": "the step kernel saturates integer VALU issue before it saturates HBM: a compute-only "
                                          "copy of it takes 105.9 us of a 114.6-117.7 us launch at 2^24 boards and 7.8 of 10.2 us "
                                          "at 2^20, a memory-only copy 105.2 / 7.65 us (tools/ubench/r3_probe.hip part A, "

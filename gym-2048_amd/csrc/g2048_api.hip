@@ -497,6 +497,13 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
     return a;
 }
 
+// Two chains pay only in rollouts long enough for both hardware queues to fill: a host thread issues a launch every
+// ~3.3 us and a half-batch kernel takes ~4 us, so the queues deepen by a fraction of a launch per step and the overlap
+// builds up over the first few dozen steps.  Measured at 2^20 boards (bench.py, us per step, two chains vs one):
+// k = 20: 9.8-10.2 vs 9.3-9.7; 32: 9.46 vs 9.16; 48: 8.85 vs 9.25; 64: 8.69 vs 9.04; 96: 8.52 vs 9.11; 160: 8.32 vs
+// 8.92; 1 000: 8.00 vs 9.08 (profiles/r04_s_chains_by_k.txt).  Shorter rollouts run as one chain.
+constexpr uint32_t kTwoChainMinSteps = 48;
+
 static int ensure_side_chain(g2048_engine *e)
 {
     if (e->side)
@@ -546,7 +553,7 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     //      are whole blocks of work.
     const uint32_t n = static_cast<uint32_t>(e->n);
     const uint32_t first_half = (n / 2u) & ~255u;
-    bool two = e->chains == 2 && e->side && !e->st.rng && k_steps >= 2 && first_half >= 256u;
+    bool two = e->chains == 2 && e->side && !e->st.rng && k_steps >= kTwoChainMinSteps && first_half >= 256u;
     if (two) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) != hipSuccess) {
@@ -585,6 +592,10 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     G2048_HIP(hipStreamWaitEvent(e->side_stream, e->fork_event, 0));
     SideLauncher *w = e->side;
     const int dtype = io->action_dtype;
+    // The caller's chain gets a HEAD START of one launch (~3.3 us of host time, about half a half-batch kernel): two
+    // chains that start together run their load phases together, like one big kernel, and only drift apart over
+    // hundreds of steps; started half a period apart they overlap from the first step.
+    hipError_t mine = g2048::launch_step(part_of(args_of(0), dtype, 0u, first_half), dtype, s);
     const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n]() -> int {
         if (hipSetDevice(e->device) != hipSuccess)
             return G2048_ERR_HIP;
@@ -602,8 +613,7 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         }
         return G2048_OK;
     });
-    hipError_t mine = hipSuccess;
-    for (uint32_t j = 0; j < k_steps && mine == hipSuccess; ++j)
+    for (uint32_t j = 1; j < k_steps && mine == hipSuccess; ++j)
         mine = g2048::launch_step(part_of(args_of(j), dtype, 0u, first_half), dtype, s);
     const int theirs = w->wait(ticket); // (the side thread has ISSUED its launches; nothing waits for the device here)
     if (theirs != G2048_OK)

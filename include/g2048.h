@@ -204,8 +204,9 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
  * tail of the other's: 9.4 -> 8.2 us per step at 2^20 boards, 5.6 -> 4.8 at 2^19, nothing below 2^19 or at 2^24
  * (tools/ubench/overlap.hip).  The side stream is forked from and joined back into `stream` with events inside every
  * g2048_rollout call, so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with
- * k_steps >= 2 and at least 512 boards; everything else (g2048_step, numpy-RNG mode, a capturing stream) runs as one
- * chain.  Default: 1. */
+ * k_steps >= 48 (the overlap builds up over the first few dozen steps: at k = 20 two chains are 5 % SLOWER than one, at
+ * k = 48 4 % faster, at k = 1 000 12 % faster) and at least 512 boards; everything else (g2048_step, shorter rollouts,
+ * numpy-RNG mode, a capturing stream) runs as one chain.  Default: 1. */
 int g2048_set_chains(g2048_engine *e, int chains);
 int g2048_get_chains(const g2048_engine *e);
 
