@@ -165,7 +165,8 @@ def traffic_for_current_sources(boards: int):
         return None, {"profile": None}
     prov = {"profile": t.get("profile"), "profiled_csrc": t.get("csrc_sha16"), "current_csrc": csrc_hash()}
     if t.get("csrc_sha16") == prov["current_csrc"] and t.get("kernel_trace_avg_us"):
-        # the rocprofv3 --kernel-trace --stats average of the committed profile of THESE sources (cross-check of launch_us)
+        # the rocprofv3 --kernel-trace --stats average of the committed profile of THESE sources, taken from the ONE-CHAIN
+        # form (`bench.py --chains 1`: one whole-batch launch per step): the cross-check of extras.single_chain.launch_us
         prov["kernel_trace_avg_us"] = t["kernel_trace_avg_us"]
         prov["kernel_trace_dispatches"] = t.get("kernel_trace_dispatches")
     if boards != (1 << 20) or t.get("csrc_sha16") != prov["current_csrc"]:

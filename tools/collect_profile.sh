@@ -22,6 +22,9 @@ PY
 cp $S/traffic.json profiles/${T}_traffic.json
 cp $S/traffic.json profiles/traffic_latest.json
 cp $S/bench_under_rocprof.json profiles/${T}_bench_under_rocprof.json
+[ -f $S/summary_two_chains.txt ] && cp $S/summary_two_chains.txt profiles/${T}_two_chains_summary.txt
+[ -f $S/kernel_stats_two_chains.csv ] && cp $S/kernel_stats_two_chains.csv profiles/${T}_kernel_stats_two_chains.csv
+[ -f $S/bench_two_chains_under_rocprof.json ] && cp $S/bench_two_chains_under_rocprof.json profiles/${T}_bench_two_chains_under_rocprof.json
 [ -f $S/kernel_stats_extras.csv ] && cp $S/kernel_stats_extras.csv profiles/${T}_kernel_stats_extras.csv
 [ -f $S/summary_obs_kernel.txt ] && cp $S/summary_obs_kernel.txt profiles/${T}_obs_kernel_summary.txt
 [ -f $S/bench_extras_under_rocprof.json ] && cp $S/bench_extras_under_rocprof.json profiles/${T}_bench_extras_under_rocprof.json

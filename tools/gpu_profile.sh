@@ -9,7 +9,10 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-BENCH="python bench.py --steps 200 --warmup 20 --no-extras $*"
+# The per-kernel evidence (kernel-trace statistics, PMC traffic) is taken from the ONE-CHAIN form of the benchmark: one
+# whole-batch launch per step, kernels strictly one after the other, so a kernel's duration is a launch time.  The
+# default two-chain form (half-batch kernels of two streams in flight together) gets its own kernel trace below.
+BENCH="python bench.py --chains 1 --steps 200 --warmup 20 --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/stats -o r -- $BENCH > $O/stats.log 2>&1
 cp $O/stats/r_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/pmc_sq1 -o r -- $BENCH > $O/pmc_sq1.log 2>&1
@@ -21,6 +24,12 @@ rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_DRAM_32B -d $O/pmc_rd32 -o r -- $BE
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_WRITE_DRAM_32B -d $O/pmc_wr32 -o r -- $BENCH > $O/pmc_wr32.log 2>&1
 python tools/rocpd_summary.py $O/stats/r_results.db $O/pmc_sq1/r_results.db $O/pmc_sq2/r_results.db $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_tcc/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > $O/summary.txt 2>&1
 python tools/rocpd_summary.py --traffic-json $O/traffic.json --profile-tag $TAG --csrc-hash $(python -c "import bench; print(bench.csrc_hash())") $O/pmc_fetch/r_results.db $O/pmc_write/r_results.db $O/pmc_rd32/r_results.db $O/pmc_wr32/r_results.db > /dev/null 2>&1
+# the default form: two chains.  Kernel trace + how many step kernels are in flight + the aggregate rate over the trains
+BENCH2="python bench.py --chains 2 --steps 200 --warmup 20 --no-extras $*"
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/stats2 -o r -- $BENCH2 > $O/stats2.log 2>&1
+cp $O/stats2/r_kernel_stats.csv $O/kernel_stats_two_chains.csv 2>/dev/null
+python tools/rocpd_summary.py --concurrency $O/stats2/r_results.db > $O/summary_two_chains.txt 2>&1
+grep -h '"metric"' $O/stats2.log > $O/bench_two_chains_under_rocprof.json
 # the same with the extras (the observation-writing step kernel, fused rollouts, the 2^24 streaming run, ...):
 # kernel-trace statistics of every kernel, and the HBM traffic counters of the step kernel that writes observations
 BENCHX="python bench.py --steps 200 --warmup 20 --cpu-seconds 1 $*"

@@ -12,6 +12,43 @@ import sqlite3
 import statistics
 
 
+def concurrency(k, name, bytes_per_item):
+    """Kernels of one name that run CONCURRENTLY (two launch chains on two streams): a per-kernel average duration says
+    nothing about throughput then.  Per grid size: dispatches, mean duration; over all of them, inside the trains (gaps
+    longer than 50 us split trains): the time with 0 / 1 / 2+ of them in flight, and the aggregate rate = work items
+    (grid_x lanes = boards) of the kernels of a train / the train's span."""
+    by_grid = {}
+    for st, en, du, gx, *_ in k:
+        by_grid.setdefault(gx, []).append(du / 1e3)
+    for gx, d in sorted(by_grid.items()):
+        print(f"   grid {gx:>9d}: {len(d):6d} dispatches, mean duration {statistics.mean(d):7.3f} us")
+    events = sorted([(st, 1) for st, *_ in k] + [(en, -1) for _, en, *_ in k])
+    inflight, last, hist = 0, events[0][0], {}
+    for t, delta in events:
+        if inflight > 0 or t - last < 50_000:          # (idle gaps between trains are not "0 in flight inside a train")
+            hist[min(inflight, 2)] = hist.get(min(inflight, 2), 0) + (t - last)
+        last, inflight = t, inflight + delta
+    tot = sum(hist.values()) or 1
+    print("   time with n kernels in flight (inside trains): " + ", ".join(f"{n}{'+' if n == 2 else ''}: {100 * v / tot:.1f} %" for n, v in sorted(hist.items())))
+    # trains: maximal runs of dispatches whose start is < 50 us after the previous end of ANY of them
+    trains, cur_start, cur_end, cur_items, cur_n = [], None, None, 0, 0
+    for st, en, du, gx, *_ in sorted(k):
+        if cur_start is not None and st - cur_end > 50_000:
+            trains.append((cur_start, cur_end, cur_items, cur_n))
+            cur_start = None
+        if cur_start is None:
+            cur_start, cur_end, cur_items, cur_n = st, en, 0, 0
+        cur_end, cur_items, cur_n = max(cur_end, en), cur_items + gx, cur_n + 1
+    trains.append((cur_start, cur_end, cur_items, cur_n))
+    big = [t for t in trains if t[3] >= 100]
+    if big:
+        rate = [t[2] / ((t[1] - t[0]) / 1e9) for t in big]
+        items, span = sum(t[2] for t in big), sum(t[1] - t[0] for t in big)
+        print(f"   trains of >= 100 dispatches: {len(big)}; aggregate {items / (span / 1e9):.4e} boards/s "
+              f"= {bytes_per_item * items / (span / 1e9) / 1e9:.0f} GB/s algorithmic ({bytes_per_item} B per board-step), "
+              f"i.e. {span / 1e3 / (items / (1 << 20)):.3f} us per 2^20 board-steps; best train {max(rate):.4e} boards/s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dbs", nargs="+")
@@ -20,6 +57,8 @@ def main():
                     help="write HBM bytes per launch of --kernel from FETCH_SIZE/WRITE_SIZE (+ DRAM_32B cross-check)")
     ap.add_argument("--profile-tag", default=None, help="name of the profile the traffic file belongs to")
     ap.add_argument("--csrc-hash", default=None, help="bench.csrc_hash() of the sources that were profiled")
+    ap.add_argument("--concurrency", action="store_true", help="kernels in flight + aggregate throughput of --kernel (two-chain runs)")
+    ap.add_argument("--bytes-per-item", type=int, default=38, help="algorithmic bytes per board-step for the aggregate rate")
     args = ap.parse_args()
     collected = {}
     for path in args.dbs:
@@ -41,6 +80,8 @@ def main():
                   f"min {min(d):.3f} max {max(d):.3f}")
             if gaps:
                 print(f"   gap to next dispatch us: mean {statistics.mean(gaps):.3f} median {statistics.median(gaps):.3f}")
+            if args.concurrency:
+                concurrency(k, args.kernel, args.bytes_per_item)
         try:
             pmc = list(cur.execute("select counter_name, avg(value), count(*) from counters_collection "
                                    "where kernel_name like ? group by counter_name", (f"%{args.kernel}%",)))
