@@ -152,6 +152,8 @@ struct g2048_engine {
     int chains = 1;
     hipStream_t side_stream = nullptr;
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    unsigned long long *chain_flags = nullptr; // device memory: [0] fork ticket, [16] join ticket (own cache lines)
+    unsigned long long chain_seq = 0;
     SideLauncher *side = nullptr;
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
@@ -338,6 +340,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipEventDestroy(e->fork_event);
         if (e->join_event)
             (void)hipEventDestroy(e->join_event);
+        if (e->chain_flags)
+            (void)hipFree(e->chain_flags);
         if (e->st.rng)
             (void)hipFree(e->st.rng);
         if (e->scratch)
@@ -497,12 +501,12 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
     return a;
 }
 
-// Two chains pay only in rollouts long enough for both hardware queues to fill: a host thread issues a launch every
-// ~3.3 us and a half-batch kernel takes ~4 us, so the queues deepen by a fraction of a launch per step and the overlap
-// builds up over the first few dozen steps.  Measured at 2^20 boards (bench.py, us per step, two chains vs one):
-// k = 20: 9.8-10.2 vs 9.3-9.7; 32: 9.46 vs 9.16; 48: 8.85 vs 9.25; 64: 8.69 vs 9.04; 96: 8.52 vs 9.11; 160: 8.32 vs
-// 8.92; 1 000: 8.00 vs 9.08 (profiles/r04_s_chains_by_k.txt).  Shorter rollouts run as one chain.
-constexpr uint32_t kTwoChainMinSteps = 48;
+// Two chains cost a fixed ~6 us per rollout more than one (the hand-off to the side thread, the two flag crossings) and
+// save ~1.2 us per step at 2^20 boards: HIP-event time of a rollout of k steps, fitted over k = 8 .. 128
+// (tools/chain_fixed_cost.py, profiles/r04_v_chain_fixed_cost.txt): one chain 9.10 us/step + 12.9 us, two chains
+// 7.91 us/step + 18.6 us (with HIP events instead of the flag kernels: + 35.3 us, and the crossover was at k ~ 40).
+// k = 8 is a tie, k = 16 is 8 % faster; shorter rollouts run as one chain.
+constexpr uint32_t kTwoChainMinSteps = 12;
 
 static int ensure_side_chain(g2048_engine *e)
 {
@@ -511,6 +515,8 @@ static int ensure_side_chain(g2048_engine *e)
     G2048_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     G2048_HIP(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
     G2048_HIP(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
+    G2048_HIP(hipMalloc(reinterpret_cast<void **>(&e->chain_flags), 256));
+    G2048_HIP(hipMemset(e->chain_flags, 0, 256));
     SideLauncher *w = new (std::nothrow) SideLauncher;
     if (!w)
         return fail(G2048_ERR_NOMEM, "out of host memory");
@@ -553,7 +559,12 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     //      are whole blocks of work.
     const uint32_t n = static_cast<uint32_t>(e->n);
     const uint32_t first_half = (n / 2u) & ~255u;
-    bool two = e->chains == 2 && e->side && !e->st.rng && k_steps >= kTwoChainMinSteps && first_half >= 256u;
+    static const uint32_t min_steps = [] { // (G2048_TWO_CHAIN_MIN_STEPS: measurement knob, tools only)
+        const char *v = std::getenv("G2048_TWO_CHAIN_MIN_STEPS");
+        const long x = v ? std::atol(v) : 0;
+        return x >= 2 ? static_cast<uint32_t>(x) : kTwoChainMinSteps;
+    }();
+    bool two = e->chains == 2 && e->side && !e->st.rng && k_steps >= min_steps && first_half >= 256u;
     if (two) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) != hipSuccess) {
@@ -587,28 +598,39 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         }
         return G2048_OK;
     }
-    // fork: the side stream starts where the caller's stream stands
-    G2048_HIP(hipEventRecord(e->fork_event, s));
-    G2048_HIP(hipStreamWaitEvent(e->side_stream, e->fork_event, 0));
+    // fork / join: the side stream starts where the caller's stream stands, and whatever the caller enqueues next runs
+    // after both halves.  By tickets in device memory (flag_set_kernel / flag_wait_kernel) -- or, G2048_CHAIN_SYNC=events,
+    // by HIP events (the portable form; ~30 us more latency per rollout on this runtime).
+    static const bool by_flags = [] {
+        const char *v = std::getenv("G2048_CHAIN_SYNC");
+        return !(v && std::strcmp(v, "events") == 0);
+    }();
+    const unsigned long long seq = ++e->chain_seq;
+    unsigned long long *fork_flag = e->chain_flags, *join_flag = e->chain_flags + 16;
+    if (by_flags) {
+        G2048_HIP(g2048::launch_flag_set(fork_flag, seq, s)); // enqueued BEFORE the side thread can enqueue its wait
+    } else {
+        G2048_HIP(hipEventRecord(e->fork_event, s));
+        G2048_HIP(hipStreamWaitEvent(e->side_stream, e->fork_event, 0));
+    }
     SideLauncher *w = e->side;
     const int dtype = io->action_dtype;
     // The caller's chain gets a HEAD START of one launch (~3.3 us of host time, about half a half-batch kernel): two
-    // chains that start together run their load phases together, like one big kernel, and only drift apart over
-    // hundreds of steps; started half a period apart they overlap from the first step.
+    // chains that start together run their load phases together, like one big kernel.
     hipError_t mine = g2048::launch_step(part_of(args_of(0), dtype, 0u, first_half), dtype, s);
-    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n]() -> int {
+    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n, fork_flag, join_flag, seq]() -> int {
         if (hipSetDevice(e->device) != hipSuccess)
             return G2048_ERR_HIP;
-        for (uint32_t j = 0; j < k_steps; ++j) {
-            const hipError_t err = g2048::launch_step(part_of(args_of(j), dtype, first_half, n - first_half), dtype, e->side_stream);
-            if (err != hipSuccess) {
-                snprintf(w->error, sizeof w->error, "launch on the side chain failed at step %u: %s", j, hipGetErrorString(err));
-                return G2048_ERR_HIP;
-            }
-        }
-        const hipError_t err = hipEventRecord(e->join_event, e->side_stream);
+        hipError_t err = by_flags ? g2048::launch_flag_wait(fork_flag, seq, e->side_stream) : hipSuccess;
+        for (uint32_t j = 0; j < k_steps && err == hipSuccess; ++j)
+            err = g2048::launch_step(part_of(args_of(j), dtype, first_half, n - first_half), dtype, e->side_stream);
+        // the join ticket goes out even after a failed launch: the caller's stream must never wait for a ticket nobody sets
+        const hipError_t tail = by_flags ? g2048::launch_flag_set(join_flag, seq, e->side_stream)
+                                         : hipEventRecord(e->join_event, e->side_stream);
+        if (err == hipSuccess)
+            err = tail;
         if (err != hipSuccess) {
-            snprintf(w->error, sizeof w->error, "hipEventRecord on the side chain failed: %s", hipGetErrorString(err));
+            snprintf(w->error, sizeof w->error, "launch on the side chain failed: %s", hipGetErrorString(err));
             return G2048_ERR_HIP;
         }
         return G2048_OK;
@@ -618,8 +640,10 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     const int theirs = w->wait(ticket); // (the side thread has ISSUED its launches; nothing waits for the device here)
     if (theirs != G2048_OK)
         return fail(theirs, "%s", w->error);
-    // join: whatever the caller enqueues next runs after both halves
-    G2048_HIP(hipStreamWaitEvent(s, e->join_event, 0));
+    if (by_flags)
+        G2048_HIP(g2048::launch_flag_wait(join_flag, seq, s));
+    else
+        G2048_HIP(hipStreamWaitEvent(s, e->join_event, 0));
     if (mine != hipSuccess)
         return fail(G2048_ERR_HIP, "launch failed: %s", hipGetErrorString(mine));
     return G2048_OK;

@@ -106,6 +106,9 @@ hipError_t launch_export_last_scores(const DeviceState &st, uint32_t n, int32_t 
 hipError_t launch_fetch(const uint4 *records, uint32_t n, uint4 *cells_out, int32_t *scores_out, unsigned long long *done_seq,
                         unsigned long long done_value, hipStream_t s);
 hipError_t launch_signal(unsigned long long *done_seq, unsigned long long done_value, hipStream_t s);
+// stream-to-stream ordering by a ticket in device memory (two-chain rollouts): set behind the work it stands for, wait (bounded) before what depends on it
+hipError_t launch_flag_set(unsigned long long *flag, unsigned long long value, hipStream_t s);
+hipError_t launch_flag_wait(const unsigned long long *flag, unsigned long long value, hipStream_t s);
 hipError_t launch_canonicalize(uint4 *boards, uint4 *next_boards, uint8_t *actions, uint32_t n, uint8_t *sym_out,
                                hipStream_t s);
 

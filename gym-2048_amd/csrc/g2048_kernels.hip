@@ -396,6 +396,30 @@ __global__ void __launch_bounds__(64) signal_kernel(unsigned long long *done_seq
     }
 }
 
+// ------------------------------------------------------------------- stream-to-stream ordering by flags
+// The two chains of a rollout (g2048_set_chains) are ordered against the caller's stream with a pair of one-wave kernels
+// instead of HIP events: flag_set_kernel publishes a ticket in device memory (agent-scope release: it runs behind the
+// work it stands for, in stream order), flag_wait_kernel on the other stream spins until the ticket is there (agent-scope
+// acquire) and the kernels behind it follow in stream order.  An event record + hipStreamWaitEvent pair costs this
+// runtime ~15 us of latency per crossing; the flag pair a few us (tools/chain_fixed_cost.py).  The wait is BOUNDED
+// (~4 s): a ticket that never comes -- a failed launch on the other side -- must not hang the device.
+__global__ void __launch_bounds__(64) flag_set_kernel(unsigned long long *flag, unsigned long long value)
+{
+    if (threadIdx.x == 0)
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(64) flag_wait_kernel(const unsigned long long *flag, unsigned long long value)
+{
+    if (threadIdx.x != 0)
+        return;
+    for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value)
+            return;
+        __builtin_amdgcn_s_sleep(16); // ~1 us between polls
+    }
+}
+
 // ---------------------------------------------------------------------------------- step
 // Game2048Env.step for every board (game2048_env.py:76-100), one launch per environment step.
 //
@@ -1614,6 +1638,18 @@ hipError_t launch_fetch(const uint4 *records, uint32_t n, uint4 *cells_out, int3
     hipLaunchKernelGGL(fetch_kernel, g, dim3(kBlock), 0, s, records, n, cells_out, scores_out, done_seq, done_value);
     if (done_seq && g.x > 1)
         hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, done_seq, done_value);
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_set(unsigned long long *flag, unsigned long long value, hipStream_t s)
+{
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, s, flag, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_wait(const unsigned long long *flag, unsigned long long value, hipStream_t s)
+{
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, flag, value);
     return hipGetLastError();
 }
 

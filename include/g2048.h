@@ -202,11 +202,13 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
  * independent (no cross-board state anywhere in game2048_env.py), so the results are bit-identical to chains = 1; what
  * changes is that two hardware queues always have a kernel waiting, so the head of one half-batch kernel overlaps the
  * tail of the other's: 9.4 -> 8.2 us per step at 2^20 boards, 5.6 -> 4.8 at 2^19, nothing below 2^19 or at 2^24
- * (tools/ubench/overlap.hip).  The side stream is forked from and joined back into `stream` with events inside every
- * g2048_rollout call, so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with
- * k_steps >= 48 (the overlap builds up over the first few dozen steps: at k = 20 two chains are 5 % SLOWER than one, at
- * k = 48 4 % faster, at k = 1 000 12 % faster) and at least 512 boards; everything else (g2048_step, shorter rollouts,
- * numpy-RNG mode, a capturing stream) runs as one chain.  Default: 1. */
+ * (tools/ubench/overlap.hip).  The side stream is forked from and joined back into `stream` inside every
+ * g2048_rollout call -- by one-wave kernels that publish / await a ticket in device memory, which cost this runtime
+ * ~17 us less latency per rollout than an event record + hipStreamWaitEvent pair (G2048_CHAIN_SYNC=events selects
+ * those) -- so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with k_steps >= 12 (two
+ * chains cost ~6 us per rollout and save ~1.2 us per step at 2^20 boards: a tie at k = 8, 8 % faster at k = 16, 12 % at
+ * k = 1 000) and at least 512 boards; everything else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing stream)
+ * runs as one chain.  Default: 1. */
 int g2048_set_chains(g2048_engine *e, int chains);
 int g2048_get_chains(const g2048_engine *e);
 

@@ -101,7 +101,7 @@ def one_case(case):
                 got = obs.cpu().numpy()
                 assert np.array_equal(got, ora.onehot().astype(got.dtype)), where
         elif kind in ("rollout", "fused"):
-            k = int(rs.integers(1, 20)) if rs.random() < 0.8 else int(rs.integers(48, 60))   # (>= 48: two chains when on)
+            k = int(rs.integers(1, 24))                 # (>= 12: two chains when on)
             acts = (eng.random_actions(k) if rs.random() < 0.5 and not numpy_mode
                     else torch.as_tensor(rs.integers(0, 4, (k, n)).astype(np.uint8)).to(dev))
             if kind == "fused":
