@@ -56,8 +56,9 @@ inline void cpu_relax()
 // issues the lower half's on the caller's stream.  One host thread issues a launch every ~3.3 us; fed by two threads,
 // both hardware queues always have a kernel waiting, and the head of one half-batch kernel (loads in flight, nothing
 // to compute yet) overlaps the tail of the other's (tools/ubench/overlap.hip: 9.4 -> 8.2 us per step at 2^20 boards).
-// The thread spins for a short while after a job (the next rollout of a training loop follows within microseconds) and
-// then sleeps on a condition variable.
+// The thread spins for 2 ms after a job or a nudge (the next rollout of a loop usually follows within microseconds) and
+// then sleeps on a condition variable; a rollout that finds it asleep runs as ONE chain and only wakes it (nudge), so a
+// cold call never pays the wake-up latency.
 struct SideLauncher {
     std::thread thread;
     std::mutex m;
@@ -68,27 +69,42 @@ struct SideLauncher {
     int result = 0;
     char error[512] = "";
 
+    std::atomic<uint64_t> nudges{0};
+
     void run()
     {
-        uint64_t seen = 0;
+        uint64_t seen = 0, seen_nudges = 0;
+        uint32_t spins = 0;
+        auto idle_since = std::chrono::steady_clock::now();
         for (;;) {
-            const auto idle_since = std::chrono::steady_clock::now();
-            uint32_t spins = 0;
-            while (posted.load() == seen && !quit.load()) {
-                cpu_relax();
-                if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(500)) {
-                    std::unique_lock<std::mutex> lock(m);
-                    sleeping.store(true);
-                    cv.wait(lock, [&] { return posted.load() != seen || quit.load(); });
-                    sleeping.store(false);
-                }
-            }
             if (quit.load())
                 return;
-            seen = posted.load();
-            result = job();
-            finished.store(seen);
+            if (posted.load() != seen) {
+                seen = posted.load();
+                result = job();
+                finished.store(seen);
+                idle_since = std::chrono::steady_clock::now();
+                continue;
+            }
+            cpu_relax();
+            if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(2)) {
+                std::unique_lock<std::mutex> lock(m);
+                sleeping.store(true);
+                cv.wait(lock, [&] { return posted.load() != seen || quit.load() || nudges.load() != seen_nudges; });
+                sleeping.store(false);
+                seen_nudges = nudges.load();
+                idle_since = std::chrono::steady_clock::now(); // awake again: spin for another window
+            }
         }
+    }
+
+    // Wake a sleeping launcher WITHOUT giving it a job: it spins for its window again, so that a rollout that follows
+    // shortly finds it ready (waking costs a thread ~50-100 us of scheduling latency -- more than a short rollout saves).
+    void nudge()
+    {
+        nudges.fetch_add(1);
+        std::lock_guard<std::mutex> lock(m);
+        cv.notify_one();
     }
 
     uint64_t post(std::function<int()> fn)
@@ -573,6 +589,10 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         } else if (st != hipStreamCaptureStatusNone) {
             two = false;
         }
+    }
+    if (e->chains == 2 && e->side && e->side->sleeping.load()) {
+        e->side->nudge(); // (any rollout wakes the launcher: e.g. a few warm-up steps ahead of a longer rollout)
+        two = false;      // ... and this call does not wait for it
     }
     const uint64_t t0 = e->t;
     e->t += k_steps;
