@@ -418,6 +418,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         sync_after_us = 0.0
+    timed_chains = eng.chains_used
     if scratch is not None:
         scratch.close()
         del scratch, sa, sr, st_, wplan, wshort
@@ -441,9 +442,7 @@ def main():
     traffic, traffic_prov = traffic_for_current_sources(B)
     working_set_mib = (B * 16 * 2 + B * 6) / 2**20
 
-    # g2048_rollout runs as two chains only when the rollout is long enough to pay for the hand-off (>= 12 steps,
-    # include/g2048.h g2048_set_chains)
-    eff_chains = 2 if (eng.chains == 2 and K >= 12) else 1
+    eff_chains = timed_chains    # what g2048_rollout did in the timed region (a two-chain engine splits only rollouts that pay)
     out = {
         "metric": ("env-steps/sec at batch=2^20 per MI355X" if B == (1 << 20) else f"env-steps/sec at batch={B} per MI355X"), "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -460,8 +459,9 @@ def main():
                              "one step_kernel launch per env-step (g2048_rollout), ") +
                             "actions/reward/terminated in [K][B] HBM rollout buffers, auto-reset fused"),
                    "chains": eff_chains,
-                   "chains_note": (f"engine set to {eng.chains} chains; rollouts shorter than 12 steps run as one chain (two chains cost "
-                                   f"~6 us per rollout and save ~1.2 us per step: profiles/r04_v_chain_fixed_cost.txt)"),
+                   "chains_note": (f"engine set to {eng.chains} chains; g2048_rollout splits a rollout only when that pays: from 12 steps while "
+                                   f"the side chain is warm, from 64 steps when it is cold -- as it is behind this benchmark's opening "
+                                   f"bracket -- (DESIGN.md 5.1a, profiles/r04_v_chain_fixed_cost.txt)"),
                    "episode_bookkeeping": ("per-wavefront counters + exact return sum (g2048_stats.return_sum); per-board "
                                            "terminal records " + ("ON (--gather full reads them)" if keep_last else
                                                                   "OFF (g2048_set_last_records(0): not needed by the summary exchange; "

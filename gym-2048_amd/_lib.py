@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class G2048Error(RuntimeError):
@@ -90,6 +90,7 @@ SIGNATURES = {
     "g2048_rollout": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_set_chains": (C.c_int, [_E, C.c_int]),
     "g2048_get_chains": (C.c_int, [_E]),
+    "g2048_get_chains_used": (C.c_int, [_E]),
     "g2048_rollout_fused": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_random": (C.c_int, [_E, _u32, _S]),
     "g2048_move": (C.c_int, [_E, C.c_void_p, _i32, C.c_int, C.c_void_p, C.c_void_p, _S]),

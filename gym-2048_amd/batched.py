@@ -156,6 +156,12 @@ class Batched2048:
         return int(self._lib.g2048_get_chains(self._h))
 
     @property
+    def chains_used(self) -> int:
+        """How many chains the most recent ``rollout`` ran as (a two-chain engine splits only rollouts that are long
+        enough to pay: from 12 steps with a warm side chain, 64 cold, 256 with its launch thread asleep)."""
+        return int(self._lib.g2048_get_chains_used(self._h))
+
+    @property
     def last_records_enabled(self) -> bool:
         return bool(self._lib.g2048_get_last_records(self._h))
 

@@ -170,6 +170,8 @@ struct g2048_engine {
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     unsigned long long *chain_flags = nullptr; // device memory: [0] fork ticket, [16] join ticket (own cache lines)
     unsigned long long chain_seq = 0;
+    int last_rollout_chains = 1; // what the most recent g2048_rollout did (g2048_get_chains_used)
+    std::chrono::steady_clock::time_point side_busy_until{}; // host-clock estimate of when the side stream last had work
     SideLauncher *side = nullptr;
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
@@ -275,7 +277,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 12; }
+int g2048_abi_version(void) { return 13; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -517,12 +519,18 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
     return a;
 }
 
-// Two chains cost a fixed ~6 us per rollout more than one (the hand-off to the side thread, the two flag crossings) and
-// save ~1.2 us per step at 2^20 boards: HIP-event time of a rollout of k steps, fitted over k = 8 .. 128
-// (tools/chain_fixed_cost.py, profiles/r04_v_chain_fixed_cost.txt): one chain 9.10 us/step + 12.9 us, two chains
-// 7.91 us/step + 18.6 us (with HIP events instead of the flag kernels: + 35.3 us, and the crossover was at k ~ 40).
-// k = 8 is a tie, k = 16 is 8 % faster; shorter rollouts run as one chain.
-constexpr uint32_t kTwoChainMinSteps = 12;
+// When do two chains pay?  Warm -- the side stream and its launch thread were in use microseconds ago -- they cost a
+// fixed ~6 us per rollout more than one chain and save ~1.2 us per step at 2^20 boards: HIP-event time of a rollout of k
+// steps, fitted over k = 8 .. 128 right behind a 128-step rollout (tools/chain_fixed_cost.py,
+// profiles/r04_v_chain_fixed_cost.txt): one chain 9.10 us/step + 12.9 us, two chains 7.91 us/step + 18.6 us (with HIP
+// events instead of the ticket kernels: + 35.3 us); k = 8 is a tie, k = 16 is 8 % faster.  COLD it is another matter: a
+// hardware queue that has idled for a few hundred microseconds starts its first kernel ~40 us late (bench.py's 20-step
+// region behind two process-group barriers: 234 us with two chains, 194 with one), and a sleeping launch thread takes
+// 50-100 us to wake.  Hence: warm, two chains from kTwoChainMinSteps; cold, only from kTwoChainColdMinSteps, where
+// 40 us are a few per cent; launcher asleep, only from kTwoChainAsleepMinSteps -- shorter rollouts run as one chain
+// and merely wake it.
+constexpr uint32_t kTwoChainMinSteps = 12, kTwoChainColdMinSteps = 64, kTwoChainAsleepMinSteps = 256;
+constexpr double kSideWarmWindowUs = 100.0; // after the estimated end of the side chain's last work
 
 static int ensure_side_chain(g2048_engine *e)
 {
@@ -538,6 +546,17 @@ static int ensure_side_chain(g2048_engine *e)
         return fail(G2048_ERR_NOMEM, "out of host memory");
     w->thread = std::thread([w] { w->run(); });
     e->side = w;
+    // prime it: a thread's first HIP calls set up per-thread runtime state (tens of microseconds) -- here, not in
+    // somebody's first two-chain rollout
+    const uint64_t ticket = w->post([e]() -> int {
+        if (hipSetDevice(e->device) != hipSuccess)
+            return G2048_ERR_HIP;
+        for (int k = 0; k < 4; ++k)
+            (void)g2048::launch_flag_set(e->chain_flags + 32, 0ull, e->side_stream);
+        return hipStreamSynchronize(e->side_stream) == hipSuccess ? G2048_OK : G2048_ERR_HIP;
+    });
+    if (w->wait(ticket) != G2048_OK)
+        return fail(G2048_ERR_HIP, "the side launch thread could not reach device %d", e->device);
     return G2048_OK;
 }
 
@@ -557,6 +576,7 @@ int g2048_set_chains(g2048_engine *e, int chains)
 }
 
 int g2048_get_chains(const g2048_engine *e) { return e ? e->chains : 0; }
+int g2048_get_chains_used(const g2048_engine *e) { return e ? e->last_rollout_chains : 0; }
 
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream)
@@ -575,12 +595,11 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     //      are whole blocks of work.
     const uint32_t n = static_cast<uint32_t>(e->n);
     const uint32_t first_half = (n / 2u) & ~255u;
-    static const uint32_t min_steps = [] { // (G2048_TWO_CHAIN_MIN_STEPS: measurement knob, tools only)
-        const char *v = std::getenv("G2048_TWO_CHAIN_MIN_STEPS");
-        const long x = v ? std::atol(v) : 0;
-        return x >= 2 ? static_cast<uint32_t>(x) : kTwoChainMinSteps;
-    }();
-    bool two = e->chains == 2 && e->side && !e->st.rng && k_steps >= min_steps && first_half >= 256u;
+    // (G2048_TWO_CHAIN_MIN_STEPS: measurement / test knob -- split every rollout of at least that many steps; read per
+    //  call, so a test can set it at any time)
+    const char *forced = e->chains == 2 ? std::getenv("G2048_TWO_CHAIN_MIN_STEPS") : nullptr;
+    const long forced_min_steps = forced ? std::atol(forced) : 0l;
+    bool two = e->chains == 2 && e->side && !e->st.rng && first_half >= 256u && k_steps >= 2;
     if (two) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) != hipSuccess) {
@@ -590,10 +609,16 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
             two = false;
         }
     }
-    if (e->chains == 2 && e->side && e->side->sleeping.load()) {
-        e->side->nudge(); // (any rollout wakes the launcher: e.g. a few warm-up steps ahead of a longer rollout)
-        two = false;      // ... and this call does not wait for it
+    if (two) {
+        const bool asleep = e->side->sleeping.load();
+        const bool warm = !asleep && std::chrono::steady_clock::now() < e->side_busy_until;
+        const uint32_t need = forced_min_steps >= 2 ? static_cast<uint32_t>(forced_min_steps)
+                              : asleep ? kTwoChainAsleepMinSteps : warm ? kTwoChainMinSteps : kTwoChainColdMinSteps;
+        if (asleep)
+            e->side->nudge(); // any rollout wakes the launcher: the next one finds it spinning
+        two = k_steps >= need;
     }
+    e->last_rollout_chains = two ? 2 : 1;
     const uint64_t t0 = e->t;
     e->t += k_steps;
     e->fresh = 0;
@@ -664,6 +689,9 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         G2048_HIP(g2048::launch_flag_wait(join_flag, seq, s));
     else
         G2048_HIP(hipStreamWaitEvent(s, e->join_event, 0));
+    // the side stream has ~k_steps half-batch kernels ahead of it (they are only enqueued): warm until they are done + a bit
+    e->side_busy_until = std::chrono::steady_clock::now() +
+                         std::chrono::microseconds(static_cast<long>(k_steps * (4.0e-6 * n + 0.5) + kSideWarmWindowUs));
     if (mine != hipSuccess)
         return fail(G2048_ERR_HIP, "launch failed: %s", hipGetErrorString(mine));
     return G2048_OK;

@@ -205,12 +205,15 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
  * (tools/ubench/overlap.hip).  The side stream is forked from and joined back into `stream` inside every
  * g2048_rollout call -- by one-wave kernels that publish / await a ticket in device memory, which cost this runtime
  * ~17 us less latency per rollout than an event record + hipStreamWaitEvent pair (G2048_CHAIN_SYNC=events selects
- * those) -- so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with k_steps >= 12 (two
- * chains cost ~6 us per rollout and save ~1.2 us per step at 2^20 boards: a tie at k = 8, 8 % faster at k = 16, 12 % at
- * k = 1 000) and at least 512 boards; everything else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing stream)
- * runs as one chain.  Default: 1. */
+ * those) -- so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with at least 512
+ * boards, when the rollout is long enough to pay: from 12 steps while the side chain is WARM (used within the last
+ * ~100 us: two chains cost ~6 us per rollout and save ~1.2 us per step at 2^20 boards), from 64 steps when it is COLD (an
+ * idle hardware queue starts its first kernel ~40 us late), from 256 steps when the launch thread has gone to sleep (2 ms
+ * after its last job; any rollout wakes it).  Everything else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing
+ * stream) runs as one chain; g2048_get_chains_used tells what the most recent g2048_rollout did.  Default: 1. */
 int g2048_set_chains(g2048_engine *e, int chains);
 int g2048_get_chains(const g2048_engine *e);
+int g2048_get_chains_used(const g2048_engine *e);
 
 /* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /
  * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead

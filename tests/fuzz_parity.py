@@ -12,8 +12,12 @@ reward, max_tile, auto_reset; then 12-40 calls chosen among
 and after every call the boards, scores, last returns, episode counts and the exact return sum (both statistics flavours)
     python tests/fuzz_parity.py [seconds=120] [seed=0]"""
 import ctypes as C
+import os
 import sys
 import time
+
+os.environ.setdefault("G2048_TWO_CHAIN_MIN_STEPS", "2")   # two-chain engines split EVERY rollout of >= 2 steps (the
+                                                          # product only does so for long or back-to-back rollouts)
 
 sys.path.insert(0, ".")
 import numpy as np

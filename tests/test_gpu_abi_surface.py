@@ -283,7 +283,7 @@ def test_two_chain_rollout_is_bit_identical(torch_cuda, n):
     from gym2048_amd.batched import Batched2048
     from oracle import OracleBatch
     import ctypes as C
-    seed, k = 21, 17                                    # (rollouts shorter than 12 steps run as one chain)
+    seed, k = 21, 70                                    # (a cold engine runs rollouts shorter than 64 steps as one chain)
     two, one, ora = Batched2048(n, seed=seed, chains=2), Batched2048(n, seed=seed, chains=1), OracleBatch(n, seed)
     assert two.chains == 2 and one.chains == 1
     for e in (two, one, ora):
@@ -335,6 +335,13 @@ def test_two_chain_rollout_is_bit_identical(torch_cuda, n):
         two.step(None)                                             # a single-chain call in between
         one.step(None)
         ora.step(None)
+        # a SHORT rollout right behind a long one: the side chain is warm, so 16 steps go out as two chains as well
+        r2, r1 = torch.zeros((16, n), dtype=torch.float32, device=dev), torch.zeros((16, n), dtype=torch.float32, device=dev)
+        two.rollout(16, reward=r2)
+        one.rollout(16, reward=r1)
+        for j in range(16):
+            ora.step(None)
+            assert np.array_equal(r2[j].cpu().numpy(), ora.reward) and np.array_equal(r1[j].cpu().numpy(), ora.reward), (rep, j)
     assert torch.equal(two.records(), one.records()) and torch.equal(two.last_records(), one.last_records())
     two.close()
     one.close()
