@@ -536,7 +536,15 @@ static int ensure_side_chain(g2048_engine *e)
 {
     if (e->side)
         return G2048_OK;
-    G2048_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    {
+        // The side stream is created at the HIGHEST priority the device offers.  In a process that also holds an RCCL
+        // communicator (dozens of hardware queues) a normal-priority side queue shares its slot by time slices and the
+        // two chains stop overlapping: 10.9-11.1 us per step instead of 8.0 at 2^20 boards, worse than one chain (9.1);
+        // with the priority it is 8.0 with or without RCCL (bench.py, forced one-rank process group, K = 400).
+        int least = 0, greatest = 0;
+        G2048_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        G2048_HIP(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, greatest));
+    }
     G2048_HIP(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
     G2048_HIP(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
     G2048_HIP(hipMalloc(reinterpret_cast<void **>(&e->chain_flags), 256));
