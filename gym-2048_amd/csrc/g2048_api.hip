@@ -522,8 +522,9 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
 // When do two chains pay?  Warm -- the side stream and its launch thread were in use microseconds ago -- they cost a
 // fixed ~6 us per rollout more than one chain and save ~1.2 us per step at 2^20 boards: HIP-event time of a rollout of k
 // steps, fitted over k = 8 .. 128 right behind a 128-step rollout (tools/chain_fixed_cost.py,
-// profiles/r04_v_chain_fixed_cost.txt): one chain 9.10 us/step + 12.9 us, two chains 7.91 us/step + 18.6 us (with HIP
-// events instead of the ticket kernels: + 35.3 us); k = 8 is a tie, k = 16 is 8 % faster.  COLD it is another matter: a
+// profiles/r04_v_chain_fixed_cost.txt; two boxes): one chain 9.10 us/step + 12.9 us (8.92 + 21.0), two chains
+// 7.91 us/step + 18.6 us (8.07 + 25.0; with HIP events instead of the ticket kernels: + 35.3 / + 46.3 us); k = 8 is a
+// tie, k = 16 is 3-8 % faster.  COLD it is another matter: a
 // hardware queue that has idled for a few hundred microseconds starts its first kernel ~40 us late (bench.py's 20-step
 // region behind two process-group barriers: 234 us with two chains, 194 with one), and a sleeping launch thread takes
 // 50-100 us to wake.  Hence: warm, two chains from kTwoChainMinSteps; cold, only from kTwoChainColdMinSteps, where
