@@ -138,6 +138,23 @@ struct SideLauncher {
     }
 };
 
+// ONE side chain per device and process, shared by every engine on that device that runs two chains: the side stream
+// (highest priority), its launch thread, and the time its last work is expected to end.  Shared so that it stays WARM:
+// a stream that has idled for a few hundred milliseconds starts its next kernels late (a forced two-chain 20-step
+// rollout takes 175 us after 0.2 ms of idle, 184-186 after 5-50 ms, 223 after 300 ms -- one chain: 195-209;
+// tools/chain_gap_probe.py), and e.g. a warm-up on one engine should leave the chain ready for the next engine.  `use`
+// serialises the engines' rollouts on it (an engine itself is single-threaded by contract).
+struct SideChain {
+    SideLauncher launcher;
+    hipStream_t stream = nullptr;
+    std::mutex use;
+    std::chrono::steady_clock::time_point busy_until{};
+    int device = 0, refs = 0;
+};
+
+std::mutex g_side_mutex;
+SideChain *g_side[64] = {};
+
 constexpr uint64_t kStateMagic = 0x3376383430324700ull; // "\0G2048v3": layout 3 = records carry the score, 4-word episode slots
 
 } // namespace
@@ -166,13 +183,11 @@ struct g2048_engine {
     unsigned long long done_count = 0;
     // two-chain rollouts (g2048_set_chains): the side stream, its fork / join events and its launch thread
     int chains = 1;
-    hipStream_t side_stream = nullptr;
+    SideChain *side = nullptr; // the device's shared side chain (a reference is held while chains == 2 was ever set)
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     unsigned long long *chain_flags = nullptr; // device memory: [0] fork ticket, [16] join ticket (own cache lines)
     unsigned long long chain_seq = 0;
     int last_rollout_chains = 1; // what the most recent g2048_rollout did (g2048_get_chains_used)
-    std::chrono::steady_clock::time_point side_busy_until{}; // host-clock estimate of when the side stream last had work
-    SideLauncher *side = nullptr;
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
@@ -346,14 +361,25 @@ int g2048_destroy(g2048_engine *e)
         return G2048_OK;
     hipError_t err = hipSuccess;
     if (e->side) {
-        e->side->stop();
-        delete e->side;
+        SideChain *dead = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_side_mutex);
+            if (--e->side->refs == 0) {
+                dead = e->side;
+                g_side[dead->device] = nullptr;
+            }
+        }
+        if (dead) {
+            dead->launcher.stop();
+            (void)hipSetDevice(dead->device);
+            if (dead->stream)
+                (void)hipStreamDestroy(dead->stream);
+            delete dead;
+        }
         e->side = nullptr;
     }
     if (e->slab) {
         (void)hipSetDevice(e->device);
-        if (e->side_stream)
-            (void)hipStreamDestroy(e->side_stream);
         if (e->fork_event)
             (void)hipEventDestroy(e->fork_event);
         if (e->join_event)
@@ -519,53 +545,73 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
     return a;
 }
 
-// When do two chains pay?  Warm -- the side stream and its launch thread were in use microseconds ago -- they cost a
-// fixed ~6 us per rollout more than one chain and save ~1.2 us per step at 2^20 boards: HIP-event time of a rollout of k
-// steps, fitted over k = 8 .. 128 right behind a 128-step rollout (tools/chain_fixed_cost.py,
-// profiles/r04_v_chain_fixed_cost.txt; two boxes): one chain 9.10 us/step + 12.9 us (8.92 + 21.0), two chains
-// 7.91 us/step + 18.6 us (8.07 + 25.0; with HIP events instead of the ticket kernels: + 35.3 / + 46.3 us); k = 8 is a
-// tie, k = 16 is 3-8 % faster.  COLD it is another matter: a
-// hardware queue that has idled for a few hundred microseconds starts its first kernel ~40 us late (bench.py's 20-step
-// region behind two process-group barriers: 234 us with two chains, 194 with one), and a sleeping launch thread takes
-// 50-100 us to wake.  Hence: warm, two chains from kTwoChainMinSteps; cold, only from kTwoChainColdMinSteps, where
-// 40 us are a few per cent; launcher asleep, only from kTwoChainAsleepMinSteps -- shorter rollouts run as one chain
-// and merely wake it.
-constexpr uint32_t kTwoChainMinSteps = 12, kTwoChainColdMinSteps = 64, kTwoChainAsleepMinSteps = 256;
-constexpr double kSideWarmWindowUs = 100.0; // after the estimated end of the side chain's last work
+// When do two chains pay?  WARM -- the device's side chain had work within the last ~50 ms -- they cost a fixed ~6 us per
+// rollout more than one chain and save ~1.2 us per step at 2^20 boards: HIP-event time of a rollout of k steps, fitted
+// over k = 8 .. 128 right behind a 128-step rollout (tools/chain_fixed_cost.py, profiles/r04_v_chain_fixed_cost.txt; two
+// boxes): one chain 9.10 us/step + 12.9 us (8.92 + 21.0), two chains 7.91 us/step + 18.6 us (8.07 + 25.0; with HIP events
+// instead of the ticket kernels: + 35.3 / + 46.3 us); k = 8 is a tie, k = 16 is 3-8 % faster.  A 20-step two-chain
+// rollout after X of idle (tools/chain_gap_probe.py, profiles/r04_aa_chain_gap_probe.txt; one chain: 188-209 us):
+// X = 0.2 ms 175 us, 5 ms 184 (the launch thread asleep by then: waking it costs ~10 us), 50 ms 186, 300 ms 223 -- COLD,
+// the side stream's first kernels start late.  Hence: warm, two chains from kTwoChainMinSteps; cold, only from
+// kTwoChainColdMinSteps, where 40 us are a few per cent.
+constexpr uint32_t kTwoChainMinSteps = 12, kTwoChainColdMinSteps = 64;
+constexpr double kSideWarmWindowUs = 50000.0; // after the estimated end of the side chain's last work
 
 static int ensure_side_chain(g2048_engine *e)
 {
     if (e->side)
         return G2048_OK;
-    {
+    if (e->device < 0 || e->device >= 64)
+        return fail(G2048_ERR_INVALID, "two chains are available on devices 0..63");
+    if (!e->chain_flags) { // the engine's own fork / join tickets (and events, for G2048_CHAIN_SYNC=events)
+        G2048_HIP(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
+        G2048_HIP(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
+        G2048_HIP(hipMalloc(reinterpret_cast<void **>(&e->chain_flags), 256));
+        G2048_HIP(hipMemset(e->chain_flags, 0, 256));
+    }
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    SideChain *sc = g_side[e->device];
+    if (!sc) {
+        sc = new (std::nothrow) SideChain;
+        if (!sc)
+            return fail(G2048_ERR_NOMEM, "out of host memory");
+        sc->device = e->device;
         // The side stream is created at the HIGHEST priority the device offers.  In a process that also holds an RCCL
         // communicator (dozens of hardware queues) a normal-priority side queue shares its slot by time slices and the
         // two chains stop overlapping: 10.9-11.1 us per step instead of 8.0 at 2^20 boards, worse than one chain (9.1);
         // with the priority it is 8.0 with or without RCCL (bench.py, forced one-rank process group, K = 400).
         int least = 0, greatest = 0;
-        G2048_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        G2048_HIP(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, greatest));
+        hipError_t err = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (err == hipSuccess)
+            err = hipStreamCreateWithPriority(&sc->stream, hipStreamNonBlocking, greatest);
+        if (err != hipSuccess) {
+            delete sc;
+            return fail(G2048_ERR_HIP, "cannot create the side stream: %s", hipGetErrorString(err));
+        }
+        SideLauncher *w = &sc->launcher;
+        w->thread = std::thread([w] { w->run(); });
+        // prime it: a thread's first HIP calls set up per-thread runtime state (tens of microseconds) -- here, not in
+        // somebody's first two-chain rollout
+        unsigned long long *scratch_flag = e->chain_flags + 32;
+        const int dev = e->device;
+        hipStream_t side_stream = sc->stream;
+        const uint64_t ticket = w->post([dev, scratch_flag, side_stream]() -> int {
+            if (hipSetDevice(dev) != hipSuccess)
+                return G2048_ERR_HIP;
+            for (int k = 0; k < 4; ++k)
+                (void)g2048::launch_flag_set(scratch_flag, 0ull, side_stream);
+            return hipStreamSynchronize(side_stream) == hipSuccess ? G2048_OK : G2048_ERR_HIP;
+        });
+        if (w->wait(ticket) != G2048_OK) {
+            w->stop();
+            (void)hipStreamDestroy(sc->stream);
+            delete sc;
+            return fail(G2048_ERR_HIP, "the side launch thread could not reach device %d", e->device);
+        }
+        g_side[e->device] = sc;
     }
-    G2048_HIP(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
-    G2048_HIP(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
-    G2048_HIP(hipMalloc(reinterpret_cast<void **>(&e->chain_flags), 256));
-    G2048_HIP(hipMemset(e->chain_flags, 0, 256));
-    SideLauncher *w = new (std::nothrow) SideLauncher;
-    if (!w)
-        return fail(G2048_ERR_NOMEM, "out of host memory");
-    w->thread = std::thread([w] { w->run(); });
-    e->side = w;
-    // prime it: a thread's first HIP calls set up per-thread runtime state (tens of microseconds) -- here, not in
-    // somebody's first two-chain rollout
-    const uint64_t ticket = w->post([e]() -> int {
-        if (hipSetDevice(e->device) != hipSuccess)
-            return G2048_ERR_HIP;
-        for (int k = 0; k < 4; ++k)
-            (void)g2048::launch_flag_set(e->chain_flags + 32, 0ull, e->side_stream);
-        return hipStreamSynchronize(e->side_stream) == hipSuccess ? G2048_OK : G2048_ERR_HIP;
-    });
-    if (w->wait(ticket) != G2048_OK)
-        return fail(G2048_ERR_HIP, "the side launch thread could not reach device %d", e->device);
+    ++sc->refs;
+    e->side = sc;
     return G2048_OK;
 }
 
@@ -619,12 +665,12 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         }
     }
     if (two) {
-        const bool asleep = e->side->sleeping.load();
-        const bool warm = !asleep && std::chrono::steady_clock::now() < e->side_busy_until;
+        const bool asleep = e->side->launcher.sleeping.load();
+        const bool warm = std::chrono::steady_clock::now() < e->side->busy_until; // (read without the lock: a heuristic)
         const uint32_t need = forced_min_steps >= 2 ? static_cast<uint32_t>(forced_min_steps)
-                              : asleep ? kTwoChainAsleepMinSteps : warm ? kTwoChainMinSteps : kTwoChainColdMinSteps;
+                              : warm ? kTwoChainMinSteps : kTwoChainColdMinSteps;
         if (asleep)
-            e->side->nudge(); // any rollout wakes the launcher: the next one finds it spinning
+            e->side->launcher.nudge(); // any rollout wakes the launcher: the next one finds it spinning
         two = k_steps >= need;
     }
     e->last_rollout_chains = two ? 2 : 1;
@@ -659,28 +705,31 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         const char *v = std::getenv("G2048_CHAIN_SYNC");
         return !(v && std::strcmp(v, "events") == 0);
     }();
+    SideChain *sc = e->side;
+    std::lock_guard<std::mutex> side_in_use(sc->use); // (another engine of this device may be using the side chain)
+    hipStream_t side_stream = sc->stream;
     const unsigned long long seq = ++e->chain_seq;
     unsigned long long *fork_flag = e->chain_flags, *join_flag = e->chain_flags + 16;
     if (by_flags) {
         G2048_HIP(g2048::launch_flag_set(fork_flag, seq, s)); // enqueued BEFORE the side thread can enqueue its wait
     } else {
         G2048_HIP(hipEventRecord(e->fork_event, s));
-        G2048_HIP(hipStreamWaitEvent(e->side_stream, e->fork_event, 0));
+        G2048_HIP(hipStreamWaitEvent(side_stream, e->fork_event, 0));
     }
-    SideLauncher *w = e->side;
+    SideLauncher *w = &sc->launcher;
     const int dtype = io->action_dtype;
     // The caller's chain gets a HEAD START of one launch (~3.3 us of host time, about half a half-batch kernel): two
     // chains that start together run their load phases together, like one big kernel.
     hipError_t mine = g2048::launch_step(part_of(args_of(0), dtype, 0u, first_half), dtype, s);
-    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n, fork_flag, join_flag, seq]() -> int {
+    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n, fork_flag, join_flag, seq, side_stream]() -> int {
         if (hipSetDevice(e->device) != hipSuccess)
             return G2048_ERR_HIP;
-        hipError_t err = by_flags ? g2048::launch_flag_wait(fork_flag, seq, e->side_stream) : hipSuccess;
+        hipError_t err = by_flags ? g2048::launch_flag_wait(fork_flag, seq, side_stream) : hipSuccess;
         for (uint32_t j = 0; j < k_steps && err == hipSuccess; ++j)
-            err = g2048::launch_step(part_of(args_of(j), dtype, first_half, n - first_half), dtype, e->side_stream);
+            err = g2048::launch_step(part_of(args_of(j), dtype, first_half, n - first_half), dtype, side_stream);
         // the join ticket goes out even after a failed launch: the caller's stream must never wait for a ticket nobody sets
-        const hipError_t tail = by_flags ? g2048::launch_flag_set(join_flag, seq, e->side_stream)
-                                         : hipEventRecord(e->join_event, e->side_stream);
+        const hipError_t tail = by_flags ? g2048::launch_flag_set(join_flag, seq, side_stream)
+                                         : hipEventRecord(e->join_event, side_stream);
         if (err == hipSuccess)
             err = tail;
         if (err != hipSuccess) {
@@ -699,7 +748,7 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     else
         G2048_HIP(hipStreamWaitEvent(s, e->join_event, 0));
     // the side stream has ~k_steps half-batch kernels ahead of it (they are only enqueued): warm until they are done + a bit
-    e->side_busy_until = std::chrono::steady_clock::now() +
+    sc->busy_until = std::chrono::steady_clock::now() +
                          std::chrono::microseconds(static_cast<long>(k_steps * (4.0e-6 * n + 0.5) + kSideWarmWindowUs));
     if (mine != hipSuccess)
         return fail(G2048_ERR_HIP, "launch failed: %s", hipGetErrorString(mine));
