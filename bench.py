@@ -64,10 +64,11 @@ def parse_args():
     ap.add_argument("--device-warmup", type=float, default=0.25,
                     help="seconds of GPU work on a SCRATCH engine before anything is measured (clocks at their "
                          "sustained level, as in a long-running job); 0 disables")
-    ap.add_argument("--chains", type=int, choices=[1, 2], default=2,
+    ap.add_argument("--chains", type=int, choices=[1, 2], default=None,
                     help="launch chains per rollout (g2048_set_chains): 2 = the batch is cut in two and the halves run as two "
                          "chains of launches on two streams from two host threads (bit-identical results; the head of one "
-                         "half-batch kernel overlaps the tail of the other's), 1 = one launch per step on one stream")
+                         "half-batch kernel overlaps the tail of the other's), 1 = one launch per step on one stream.  Default: 2, "
+                         "except in a multi-rank run of fewer than 200 steps (see main())")
     ap.add_argument("--gather", choices=["summary", "full"], default="summary",
                     help="N > 1: what the once-per-rollout all-gather ships -- the per-rank return summary "
                          "(g2048_stats) or every board's last episodic return (int32[B])")
@@ -309,6 +310,13 @@ def main():
     # episodes / illegal ends / the exact return sum, none of which needs the per-board terminal records, so they are
     # off (g2048_set_last_records: one sparse 16-byte store per finished episode less; extras.with_last_records has the
     # same launch train with them on); --gather full ships every board's last return and keeps them.
+    if args.chains is None:
+        # Two chains by default.  Exception: short rollouts in a process that holds an RCCL communicator -- behind a
+        # two-chain 20-step train the once-per-rollout exchange (summary kernels + all-gather) takes 80-140 us in three
+        # runs out of four instead of 27 us (forced one-rank group, profiles/r04_ab_forced_dist_chains.txt; not understood
+        # yet), which costs more than the two chains save there; from a few hundred steps on they win again (K = 400:
+        # 8.09 vs 8.94 us per step including the exchange).
+        args.chains = 1 if (dist_on and backend == "nccl" and K < 200) else 2
     keep_last = args.gather == "full"
     eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset, last_records=keep_last, chains=args.chains)
     eng.reset()

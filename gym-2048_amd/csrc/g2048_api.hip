@@ -70,6 +70,10 @@ struct SideLauncher {
     char error[512] = "";
 
     std::atomic<uint64_t> nudges{0};
+    long spin_us = [] { // how long the thread spins after a job before it sleeps (G2048_SIDE_SPIN_US: measurement knob)
+        const char *v = std::getenv("G2048_SIDE_SPIN_US");
+        return v ? std::atol(v) : 2000l;
+    }();
 
     void run()
     {
@@ -87,7 +91,7 @@ struct SideLauncher {
                 continue;
             }
             cpu_relax();
-            if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(2)) {
+            if ((++spins & 0x3fu) == 0u && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(spin_us)) {
                 std::unique_lock<std::mutex> lock(m);
                 sleeping.store(true);
                 cv.wait(lock, [&] { return posted.load() != seen || quit.load() || nudges.load() != seen_nudges; });
