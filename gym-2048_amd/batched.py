@@ -158,7 +158,7 @@ class Batched2048:
     @property
     def chains_used(self) -> int:
         """How many chains the most recent ``rollout`` ran as (a two-chain engine splits only rollouts that are long
-        enough to pay: from 12 steps with a warm side chain, 64 cold, 256 with its launch thread asleep)."""
+        enough to pay: from 12 steps while the device's side chain is warm, i.e. used within the last 50 ms, 64 cold)."""
         return int(self._lib.g2048_get_chains_used(self._h))
 
     @property

@@ -57,8 +57,8 @@ inline void cpu_relax()
 // both hardware queues always have a kernel waiting, and the head of one half-batch kernel (loads in flight, nothing
 // to compute yet) overlaps the tail of the other's (tools/ubench/overlap.hip: 9.4 -> 8.2 us per step at 2^20 boards).
 // The thread spins for 2 ms after a job or a nudge (the next rollout of a loop usually follows within microseconds) and
-// then sleeps on a condition variable; a rollout that finds it asleep runs as ONE chain and only wakes it (nudge), so a
-// cold call never pays the wake-up latency.
+// then sleeps on a condition variable (waking it costs ~10 us; a rollout that finds it asleep and does not use it nudges
+// it awake for the next one).
 struct SideLauncher {
     std::thread thread;
     std::mutex m;
@@ -554,7 +554,7 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
 // over k = 8 .. 128 right behind a 128-step rollout (tools/chain_fixed_cost.py, profiles/r04_v_chain_fixed_cost.txt; two
 // boxes): one chain 9.10 us/step + 12.9 us (8.92 + 21.0), two chains 7.91 us/step + 18.6 us (8.07 + 25.0; with HIP events
 // instead of the ticket kernels: + 35.3 / + 46.3 us); k = 8 is a tie, k = 16 is 3-8 % faster.  A 20-step two-chain
-// rollout after X of idle (tools/chain_gap_probe.py, profiles/r04_aa_chain_gap_probe.txt; one chain: 188-209 us):
+// rollout after X of idle (tools/chain_gap_probe.py, profiles/r04_ab_chain_gap_probe.txt; one chain: 188-209 us):
 // X = 0.2 ms 175 us, 5 ms 184 (the launch thread asleep by then: waking it costs ~10 us), 50 ms 186, 300 ms 223 -- COLD,
 // the side stream's first kernels start late.  Hence: warm, two chains from kTwoChainMinSteps; cold, only from
 // kTwoChainColdMinSteps, where 40 us are a few per cent.

@@ -198,7 +198,8 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
 
 /* Two-chain rollouts.  With chains = 2, g2048_rollout cuts the batch in two at a block boundary and runs the halves as
  * two independent chains of launches: the lower half on the caller's stream, issued by the calling thread, the upper
- * half on an engine-owned side stream, issued by an engine-owned launch thread (created by this call).  Boards are
+ * half on the device's side stream (highest priority; one per device and process, shared by its engines, created by the
+ * first such call), issued by that side chain's own launch thread.  Boards are
  * independent (no cross-board state anywhere in game2048_env.py), so the results are bit-identical to chains = 1; what
  * changes is that two hardware queues always have a kernel waiting, so the head of one half-batch kernel overlaps the
  * tail of the other's: 9.4 -> 8.2 us per step at 2^20 boards, 5.6 -> 4.8 at 2^19, nothing below 2^19 or at 2^24
@@ -206,11 +207,12 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
  * g2048_rollout call -- by one-wave kernels that publish / await a ticket in device memory, which cost this runtime
  * ~17 us less latency per rollout than an event record + hipStreamWaitEvent pair (G2048_CHAIN_SYNC=events selects
  * those) -- so callers see ordinary stream order.  Applies to g2048_rollout in spawn-stream mode with at least 512
- * boards, when the rollout is long enough to pay: from 12 steps while the side chain is WARM (used within the last
- * ~100 us: two chains cost ~6 us per rollout and save ~1.2 us per step at 2^20 boards), from 64 steps when it is COLD (an
- * idle hardware queue starts its first kernel ~40 us late), from 256 steps when the launch thread has gone to sleep (2 ms
- * after its last job; any rollout wakes it).  Everything else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing
- * stream) runs as one chain; g2048_get_chains_used tells what the most recent g2048_rollout did.  Default: 1. */
+ * boards, when the rollout is long enough to pay: from 12 steps while the device's side chain is WARM (it had work
+ * within the last ~50 ms: two chains cost ~6 us per rollout and save ~1.2 us per step at 2^20 boards), from 64 steps when
+ * it is COLD (a stream that has idled for a few hundred milliseconds starts its first kernels ~40 us late).  Everything
+ * else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing stream) runs as one chain; g2048_get_chains_used tells
+ * what the most recent g2048_rollout did.  Engines of one device share the side chain: their rollouts take turns on it.
+ * Default: 1. */
 int g2048_set_chains(g2048_engine *e, int chains);
 int g2048_get_chains(const g2048_engine *e);
 int g2048_get_chains_used(const g2048_engine *e);
