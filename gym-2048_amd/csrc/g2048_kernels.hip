@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(64) signal_kernel(unsigned long long *done_seq
 // work it stands for, in stream order), flag_wait_kernel on the other stream spins until the ticket is there (agent-scope
 // acquire) and the kernels behind it follow in stream order.  An event record + hipStreamWaitEvent pair costs this
 // runtime ~15 us of latency per crossing; the flag pair a few us (tools/chain_fixed_cost.py).  The wait is BOUNDED
-// (~4 s): a ticket that never comes -- a failed launch on the other side -- must not hang the device.
+// (2^25 polls, about a minute -- longer than any work a caller could reasonably have queued ahead of the ticket): a
+// ticket that never comes -- a failed launch on the other side -- must not hang the device for good.
 __global__ void __launch_bounds__(64) flag_set_kernel(unsigned long long *flag, unsigned long long value)
 {
     if (threadIdx.x == 0)
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(64) flag_wait_kernel(const unsigned long long 
 {
     if (threadIdx.x != 0)
         return;
-    for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+    for (uint32_t spin = 0; spin < (1u << 25); ++spin) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value)
             return;
         __builtin_amdgcn_s_sleep(16); // ~1 us between polls
