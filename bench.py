@@ -313,9 +313,10 @@ def main():
     if args.chains is None:
         # Two chains by default.  Exception: short rollouts in a process that holds an RCCL communicator -- behind a
         # two-chain 20-step train the once-per-rollout exchange (summary kernels + all-gather) takes 80-140 us in three
-        # runs out of four instead of 27 us (forced one-rank group, profiles/r04_ab_forced_dist_chains.txt; not understood
-        # yet), which costs more than the two chains save there; from a few hundred steps on they win again (K = 400:
-        # 8.09 vs 8.94 us per step including the exchange).
+        # runs out of four instead of 27 us (forced one-rank group, profiles/r04_ab_forced_dist_chains.txt): with two
+        # threads launching, the calling thread reaches the exchange (~100 us of host work) about when the device finishes
+        # a 20-step train, so the host's latency shows; from a few hundred steps on two chains win again (K = 400: 8.09 vs
+        # 8.94 us per step including the exchange).
         args.chains = 1 if (dist_on and backend == "nccl" and K < 200) else 2
     keep_last = args.gather == "full"
     eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset, last_records=keep_last, chains=args.chains)
