@@ -154,6 +154,7 @@ struct SideChain {
     std::mutex use;
     std::chrono::steady_clock::time_point busy_until{};
     int device = 0, refs = 0;
+    int priority = 0; // of `stream`: the highest the device offers
 };
 
 std::mutex g_side_mutex;
@@ -592,6 +593,7 @@ static int ensure_side_chain(g2048_engine *e)
             delete sc;
             return fail(G2048_ERR_HIP, "cannot create the side stream: %s", hipGetErrorString(err));
         }
+        sc->priority = greatest;
         SideLauncher *w = &sc->launcher;
         w->thread = std::thread([w] { w->run(); });
         // prime it: a thread's first HIP calls set up per-thread runtime state (tens of microseconds) -- here, not in
@@ -666,6 +668,21 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
             two = false;
         } else if (st != hipStreamCaptureStatusNone) {
             two = false;
+        }
+    }
+    if (two) {
+        // A caller's stream at the side stream's own priority may be given the SAME hardware queue by the runtime, and
+        // streams that share one run in submission order: the caller's wait for the join ticket could then sit in front of
+        // the side launches it waits for.  Such a stream gets one chain.  (Streams of other priorities have their own
+        // queues; one runtime call per rollout.)
+        if (s != nullptr && !std::getenv("G2048_CHAIN_ANY_PRIORITY")) { // (the knob: to measure what the rule avoids)
+            int prio = 0;
+            if (hipStreamGetPriority(s, &prio) != hipSuccess) {
+                (void)hipGetLastError();
+                two = false;
+            } else if (prio == e->side->priority) {
+                two = false;
+            }
         }
     }
     if (two) {

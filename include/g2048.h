@@ -210,7 +210,9 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
  * boards, when the rollout is long enough to pay: from 12 steps while the device's side chain is WARM (it had work
  * within the last ~50 ms: two chains cost ~6 us per rollout and save ~1.2 us per step at 2^20 boards), from 64 steps when
  * it is COLD (a stream that has idled for a few hundred milliseconds starts its first kernels ~40 us late).  Everything
- * else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing stream) runs as one chain; g2048_get_chains_used tells
+ * else (g2048_step, shorter rollouts, numpy-RNG mode, a capturing stream, a caller's stream created at the device's
+ * highest priority -- the side stream's own: two streams of one priority may be given one hardware queue, and the ticket
+ * kernels need two) runs as one chain; g2048_get_chains_used tells
  * what the most recent g2048_rollout did.  Engines of one device share the side chain: their rollouts take turns on it.
  * Default: 1. */
 int g2048_set_chains(g2048_engine *e, int chains);

@@ -347,6 +347,47 @@ def test_two_chain_rollout_is_bit_identical(torch_cuda, n):
     one.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_chain_rollout_on_whatever_stream_the_caller_brings(torch_cuda):
+    """The caller's stream of a two-chain rollout can be any stream: the legacy default stream, torch's current stream,
+    one of MANY pool streams in use at once (more streams than hardware queues), or a HIGH-priority stream -- which has
+    the side stream's own priority and may share its hardware queue, so that rollout must go out as one chain
+    (g2048_get_chains_used) instead of parking a ticket wait in front of its ticket.  All bit-identical, none slow."""
+    torch = torch_cuda
+    import time
+    from gym2048_amd.batched import Batched2048
+    n, k, seed = 1 << 16, 70, 5
+    ref = Batched2048(n, seed=seed, chains=1)
+    ref.reset()
+    want = torch.zeros((k, n), dtype=torch.float32, device=ref.device)
+    ref.rollout(k, reward=want)
+    torch.cuda.synchronize()
+    crowd = [torch.cuda.Stream() for _ in range(12)]
+    high = torch.cuda.Stream(priority=-1)
+    cases = [("default", None, 2)] + [("pool%d" % i, st, 2) for i, st in enumerate(crowd[:3])] + [("high", high, 1)]
+    for name, st, chains in cases:
+        eng = Batched2048(n, seed=seed, chains=2)
+        got = torch.zeros((k, n), dtype=torch.float32, device=eng.device)
+        junk = [torch.zeros(1 << 18, device=eng.device) for _ in crowd]
+        t0 = time.perf_counter()
+        ctx = torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.default_stream())
+        with ctx:
+            eng.reset()
+            for c, j in zip(crowd, junk):          # every pool stream busy while the rollout is enqueued
+                with torch.cuda.stream(c):
+                    j.add_(1.0).cumsum_(0)
+            eng.rollout(k, reward=got)
+            total = got.sum()
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t0
+        assert eng.chains_used == chains, (name, eng.chains_used)
+        assert torch.equal(got, want) and float(total) == float(want.sum()), name
+        assert took < 5.0, (name, took)            # (a ticket wait that never sees its ticket gives up after ~a minute)
+        eng.close()
+    ref.close()
+
+
 def test_rollout_writes_terminal_boards(torch_cuda):
     """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
     episode and holds the board the episode ended on."""
