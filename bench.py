@@ -714,6 +714,14 @@ def main():
         except Exception as exc:  # pragma: no cover
             extras["single_env_host_steps_per_s"] = f"error: {exc}"
         out["extras"] = extras
+        sc = extras.get("single_chain")
+        if isinstance(sc, dict) and "launch_us" in sc:
+            # the KERNEL's own figure, next to the per-step one above: one whole-batch launch per step, so the HIP-event
+            # time per launch is a kernel duration -- the number a kernel trace of `bench.py --chains 1` averages
+            out["roofline"]["one_launch_per_step"] = {
+                "launch_us": sc["launch_us"], "achieved": ALGO_BYTES_PER_STEP * B / (sc["launch_us"] * 1e-6) / 1e9,
+                "frac": sc["frac_of_hbm_peak"], "launches": sc["launches"],
+                "kernel_trace_avg_us": (out["roofline"].get("traffic_provenance") or {}).get("kernel_trace_avg_us")}
         # (c) CPU legs (rank 0, N = 1 only per the contract; cheap enough to always show at N = 1)
         if world == 1:
             ge.build()
