@@ -469,8 +469,9 @@ def main():
                             "actions/reward/terminated in [K][B] HBM rollout buffers, auto-reset fused"),
                    "chains": eff_chains,
                    "chains_note": (f"engine set to {eng.chains} chains; g2048_rollout splits a rollout only when that pays: from 12 steps while "
-                                   f"the side chain is warm, from 64 steps when it is cold -- as it is behind this benchmark's opening "
-                                   f"bracket -- (DESIGN.md 5.1a, profiles/r04_v_chain_fixed_cost.txt)"),
+                                   f"the device's side chain is warm (work within the last 50 ms: here the scratch engine's warm-up, "
+                                   f"which shares it), from 64 steps when it is cold; `chains` is what the timed rollout did "
+                                   f"(g2048_get_chains_used; DESIGN.md 5.1a, profiles/r04_v_chain_fixed_cost.txt)"),
                    "episode_bookkeeping": ("per-wavefront counters + exact return sum (g2048_stats.return_sum); per-board "
                                            "terminal records " + ("ON (--gather full reads them)" if keep_last else
                                                                   "OFF (g2048_set_last_records(0): not needed by the summary exchange; "
