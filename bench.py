@@ -46,6 +46,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC: what RCCL needs across processes on this driver.  Read when the HIP runtime starts, so it is set before
+# torch is imported -- also for ranks started by somebody else's launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_STEP = 38          # board in 16 + action 1 + board out 16 + reward 4 + terminated 1
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
