@@ -339,7 +339,12 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
         delete e;
         return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", wanted, hipGetErrorString(err));
     }
+    // hipMemset of device memory only ENQUEUES the fill (on the null stream: 3 us for a call that takes 1.4 ms on 8 GiB,
+    // tools/memset_probe.py), and a caller's non-blocking stream -- every torch stream but the default one -- is not
+    // ordered behind the null stream: without the wait the engine's first kernels could run before the clear.
     err = hipMemset(e->slab, 0, e->slab_bytes);
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(nullptr);
     if (err != hipSuccess) {
         (void)hipFree(e->slab);
         delete e;
@@ -573,6 +578,7 @@ static int ensure_side_chain(g2048_engine *e)
         G2048_HIP(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
         G2048_HIP(hipMalloc(reinterpret_cast<void **>(&e->chain_flags), 256));
         G2048_HIP(hipMemset(e->chain_flags, 0, 256));
+        G2048_HIP(hipStreamSynchronize(nullptr)); // (the fill is only enqueued, and not ordered against non-blocking streams)
     }
     std::lock_guard<std::mutex> lock(g_side_mutex);
     SideChain *sc = g_side[e->device];
