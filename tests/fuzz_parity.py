@@ -10,7 +10,7 @@ reward, max_tile, auto_reset; then 12-40 calls chosen among
   step_host (host-resident I/O)
   masked reset, set_boards, set_scores, state save / restore into a second engine
 and after every call the boards, scores, last returns, episode counts and the exact return sum (both statistics flavours)
-    python tests/fuzz_parity.py [seconds=120] [seed=0]"""
+    python tests/fuzz_parity.py [seconds=120] [seed=0]          (G2048_FUZZ_STREAMS=1: every case on its own non-default stream)"""
 import ctypes as C
 import os
 import sys
@@ -182,8 +182,15 @@ def run(budget: float = 120.0, seed: int = 0) -> str:
     counts.clear()
     t0 = time.time()
     case = 0
+    # G2048_FUZZ_STREAMS=1: every case runs on a fresh NON-DEFAULT (non-blocking) torch stream instead of the default
+    # stream -- nothing in the library may rely on the ordering the null stream gives for free
+    own_streams = os.environ.get("G2048_FUZZ_STREAMS") == "1"
     while time.time() - t0 < budget:
-        one_case(case)
+        if own_streams:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                one_case(case)
+        else:
+            one_case(case)
         case += 1
     return (f"fuzz ok: {case} cases in {time.time() - t0:.0f} s, calls {dict(sorted(counts.items()))}; every output of "
             f"every call bit-exact vs the oracle")

@@ -5,9 +5,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12])
-def test_fuzz_call_mixes_vs_oracle(torch_cuda, seed):
+@pytest.mark.parametrize("seed,own_streams", [(11, False), (12, True)])
+def test_fuzz_call_mixes_vs_oracle(torch_cuda, monkeypatch, seed, own_streams):
     import fuzz_parity
+    if own_streams:                     # every case on a fresh non-default (non-blocking) stream
+        monkeypatch.setenv("G2048_FUZZ_STREAMS", "1")
     line = fuzz_parity.run(budget=12.0, seed=seed)
     assert line.startswith("fuzz ok")
     print(line)
