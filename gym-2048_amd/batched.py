@@ -103,6 +103,10 @@ class Batched2048:
             self.set_chains(chains)
         if self.rng_mode == "numpy":
             self.seed(seed)
+        # The engine may be used from ANY stream once the constructor has returned: what was enqueued here (the fills of
+        # the output buffers, set_last_records, the numpy-mode seeding) went to the constructing thread's current
+        # stream, and another stream is not ordered behind it.
+        torch.cuda.current_stream(self.device).synchronize()
 
     # ------------------------------------------------------------------ lifetime
     def close(self):

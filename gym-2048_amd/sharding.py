@@ -183,7 +183,10 @@ class LocalShards:
             comm = C.c_void_p()
             _lib.check(self._lib.g2048_comm_local_create((C.c_int * g)(*self.devices), g, C.byref(comm)))
             self._comm = comm
-        outs = [torch.empty(self.n_global, dtype=torch.int32, device=e.device) for e in self.engines]
+        outs = []
+        for e, s in zip(self.engines, self.streams):
+            with torch.cuda.stream(s):                 # allocated ON the stream that writes it: torch's caching allocator
+                outs.append(torch.empty(self.n_global, dtype=torch.int32, device=e.device))  # orders reuse per stream
         eng = (C.c_void_p * g)(*[e._h for e in self.engines])
         ptrs = (C.c_void_p * g)(*[o.data_ptr() for o in outs])
         streams = (C.c_void_p * g)(*[s.cuda_stream for s in self.streams])
