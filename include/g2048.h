@@ -142,10 +142,7 @@ int g2048_abi_version(void);
 
 /* Game2048Env.__init__ (game2048_env.py:38-58) for n_boards boards on HIP device `device`.
  * Boards are all-empty until g2048_reset.  board_offset = global index of local board 0.
- * 1 <= n_boards <= 2^32 - 256 and board_offset + n_boards <= 2^32.
- * The engine's state is cleared when g2048_create returns (the call waits for its own fills), so the first launch may
- * come on any stream, blocking or not.  g2048_destroy waits for the engine's work still in flight on any stream (it
- * frees device memory, which synchronises the device: tools/free_probe.py). */
+ * 1 <= n_boards <= 2^32 - 256 and board_offset + n_boards <= 2^32. */
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out);
 int g2048_destroy(g2048_engine *e);
 
