@@ -36,7 +36,7 @@ def run(seconds=120.0, seed=0, n_threads=3):
             rs = np.random.default_rng(seed * 100 + wid)
             stream = torch.cuda.Stream()
             while time.time() < deadline and not failures:
-                n = int(rs.choice([512, 768, 1000, 4096, 65536, 1 << 18]))
+                n = int(rs.choice([512, 768, 1000, 4096, 65536, 1 << 18, 1 << 20], p=[.2, .15, .15, .2, .15, .1, .05]))
                 s = int(rs.integers(0, 1 << 30))
                 with torch.cuda.stream(stream):
                     two, one = Batched2048(n, seed=s, chains=2), Batched2048(n, seed=s, chains=1)
@@ -54,10 +54,18 @@ def run(seconds=120.0, seed=0, n_threads=3):
                         r1 = torch.zeros((k, n), dtype=torch.float32, device=one.device)
                         d2 = torch.zeros((k, n), dtype=torch.uint8, device=two.device)
                         d1 = torch.zeros((k, n), dtype=torch.uint8, device=one.device)
-                        two.rollout(k, reward=r2, terminated=d2)
+                        extra2, extra1 = {}, {}
+                        if n <= 65536 and rs.random() < 0.3:      # sometimes every optional output rides along
+                            for ex in (extra2, extra1):
+                                ex["illegal"] = torch.zeros((k, n), dtype=torch.uint8, device=two.device)
+                                ex["highest"] = torch.zeros((k, n), dtype=torch.uint8, device=two.device)
+                                ex["terminal_boards"] = torch.zeros((k, n, 16), dtype=torch.uint8, device=two.device)
+                                ex["obs"] = torch.zeros((k, n, 16, 4, 4), dtype=torch.uint8, device=two.device) if n <= 4096 else None
+                        two.rollout(k, reward=r2, terminated=d2, **{a: b for a, b in extra2.items() if b is not None})
                         used = two.chains_used
-                        one.rollout(k, reward=r1, terminated=d1)
-                        if not (torch.equal(r2, r1) and torch.equal(d2, d1)):
+                        one.rollout(k, reward=r1, terminated=d1, **{a: b for a, b in extra1.items() if b is not None})
+                        same = all(torch.equal(extra2[a], extra1[a]) for a in extra2 if extra2[a] is not None)
+                        if not (same and torch.equal(r2, r1) and torch.equal(d2, d1)):
                             failures.append(f"worker {wid}: n={n} seed={s} k={k}: outputs differ (chains_used={used})")
                             break
                         with lock:
