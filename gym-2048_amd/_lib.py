@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class G2048Error(RuntimeError):

@@ -3,6 +3,7 @@
 #include "../../include/g2048.h"
 
 #include "g2048_kernels.h"
+#include "g2048_side_launcher.h"
 
 #include <rccl/rccl.h> // declarations only: librccl is dlopen()ed by the first g2048_comm_* call
 
@@ -18,9 +19,6 @@
 #include <mutex>
 #include <new>
 #include <thread>
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 
 namespace {
 
@@ -42,105 +40,8 @@ int fail(int code, const char *fmt, ...)
             return fail(G2048_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(err_));                       \
     } while (0)
 
-inline void cpu_relax()
-{
-#if defined(__x86_64__)
-    _mm_pause();
-#else
-    std::this_thread::yield();
-#endif
-}
-
-// The second launch thread of an engine that runs its rollouts as TWO CHAINS (g2048_set_chains): a rollout's launches
-// for the upper half of the batch are issued by this thread on the engine's side stream while the calling thread
-// issues the lower half's on the caller's stream.  One host thread issues a launch every ~3.3 us; fed by two threads,
-// both hardware queues always have a kernel waiting, and the head of one half-batch kernel (loads in flight, nothing
-// to compute yet) overlaps the tail of the other's (tools/ubench/overlap.hip: 9.4 -> 8.2 us per step at 2^20 boards).
-// The thread spins for 2 ms after a job or a nudge (the next rollout of a loop usually follows within microseconds) and
-// then sleeps on a condition variable (waking it costs ~10 us; a rollout that finds it asleep and does not use it nudges
-// it awake for the next one).
-struct SideLauncher {
-    std::thread thread;
-    std::mutex m;
-    std::condition_variable cv;
-    std::atomic<uint64_t> posted{0}, finished{0};
-    std::atomic<bool> sleeping{false}, quit{false};
-    std::function<int()> job;
-    int result = 0;
-    char error[512] = "";
-
-    std::atomic<uint64_t> nudges{0};
-    long spin_us = [] { // how long the thread spins after a job before it sleeps (G2048_SIDE_SPIN_US: measurement knob)
-        const char *v = std::getenv("G2048_SIDE_SPIN_US");
-        return v ? std::atol(v) : 2000l;
-    }();
-
-    void run()
-    {
-        uint64_t seen = 0, seen_nudges = 0;
-        uint32_t spins = 0;
-        auto idle_since = std::chrono::steady_clock::now();
-        for (;;) {
-            if (quit.load())
-                return;
-            if (posted.load() != seen) {
-                seen = posted.load();
-                result = job();
-                finished.store(seen);
-                idle_since = std::chrono::steady_clock::now();
-                continue;
-            }
-            cpu_relax();
-            if ((++spins & 0x3fu) == 0u && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(spin_us)) {
-                std::unique_lock<std::mutex> lock(m);
-                sleeping.store(true);
-                cv.wait(lock, [&] { return posted.load() != seen || quit.load() || nudges.load() != seen_nudges; });
-                sleeping.store(false);
-                seen_nudges = nudges.load();
-                idle_since = std::chrono::steady_clock::now(); // awake again: spin for another window
-            }
-        }
-    }
-
-    // Wake a sleeping launcher WITHOUT giving it a job: it spins for its window again, so that a rollout that follows
-    // shortly finds it ready (waking costs a thread ~50-100 us of scheduling latency -- more than a short rollout saves).
-    void nudge()
-    {
-        nudges.fetch_add(1);
-        std::lock_guard<std::mutex> lock(m);
-        cv.notify_one();
-    }
-
-    uint64_t post(std::function<int()> fn)
-    {
-        job = std::move(fn);
-        const uint64_t ticket = posted.fetch_add(1) + 1;
-        if (sleeping.load()) {
-            std::lock_guard<std::mutex> lock(m);
-            cv.notify_one();
-        }
-        return ticket;
-    }
-
-    int wait(uint64_t ticket)
-    {
-        while (finished.load() < ticket)
-            cpu_relax();
-        return result;
-    }
-
-    void stop()
-    {
-        if (!thread.joinable())
-            return;
-        {
-            std::lock_guard<std::mutex> lock(m);
-            quit.store(true);
-        }
-        cv.notify_one();
-        thread.join();
-    }
-};
+using g2048::SideLauncher;
+using g2048::cpu_relax;
 
 // ONE side chain per device and process, shared by every engine on that device that runs two chains: the side stream
 // (highest priority), its launch thread, and the time its last work is expected to end.  Shared so that it stays WARM:
@@ -152,13 +53,18 @@ struct SideChain {
     SideLauncher launcher;
     hipStream_t stream = nullptr;
     std::mutex use;
-    std::chrono::steady_clock::time_point busy_until{};
+    std::atomic<int64_t> busy_until_ns{0}; // steady-clock time the side stream's queued work is expected to have ended + the warm window
     int device = 0, refs = 0;
     int priority = 0; // of `stream`: the highest the device offers
 };
 
 std::mutex g_side_mutex;
 SideChain *g_side[64] = {};
+
+int64_t steady_now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 constexpr uint64_t kStateMagic = 0x3376383430324700ull; // "\0G2048v3": layout 3 = records carry the score, 4-word episode slots
 
@@ -190,8 +96,20 @@ struct g2048_engine {
     int chains = 1;
     SideChain *side = nullptr; // the device's shared side chain (a reference is held while chains == 2 was ever set)
     hipEvent_t fork_event = nullptr, join_event = nullptr;
-    unsigned long long *chain_flags = nullptr; // device memory: [0] fork ticket, [16] join ticket (own cache lines)
+    unsigned long long *chain_flags = nullptr; // device memory (256 B): [0] fork ticket, [16] join ticket (own cache lines), [24] scratch
     unsigned long long chain_seq = 0;
+    // a ticket wait that ran out (flag_wait_kernel) reports here: 64 bytes of pinned, coherent host memory, checked at
+    // the entry of every call on the engine
+    unsigned long long *chain_err_host = nullptr, *chain_err_dev = nullptr;
+    // the measurement / test knobs of the two-chain form, read from the environment by g2048_set_chains (NOT per rollout)
+    uint32_t chain_min_steps = 0;      // G2048_TWO_CHAIN_MIN_STEPS: split every rollout of at least that many steps (0: the warm / cold rule)
+    uint32_t chain_wait_polls = g2048::kFlagWaitPolls; // G2048_FLAG_WAIT_POLLS: bound of a ticket wait, ~1 us per poll
+    bool chain_any_priority = false;   // G2048_CHAIN_ANY_PRIORITY: also split on a caller's stream of the side stream's priority
+    bool chain_by_events = false;      // G2048_CHAIN_SYNC=events: fork / join by HIP events instead of tickets
+    // set when a call left the engine in a state its caller cannot know (a two-chain rollout that failed half-way):
+    // every later call fails with this message instead of continuing on half-stepped boards
+    int poisoned = 0;
+    char poison_msg[320] = "";
     int last_rollout_chains = 1; // what the most recent g2048_rollout did (g2048_get_chains_used)
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
@@ -258,6 +176,29 @@ int need_last_records(const g2048_engine *e, const char *what)
 
 size_t obs_board_bytes(int dtype) { return static_cast<size_t>(256) << (dtype < 0 ? 0 : dtype); } // 16 channels x 16 cells
 
+// Every call on an engine starts here: NULL, poisoned (a call that failed half-way), or a two-chain ticket wait that
+// ran out on the device (the chains ran unordered since: whatever the engine holds is undefined).
+int usable(const g2048_engine *e)
+{
+    if (!e)
+        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (e->poisoned)
+        return fail(G2048_ERR_HIP, "%s", e->poison_msg);
+    if (e->chain_err_host && __atomic_load_n(e->chain_err_host, __ATOMIC_ACQUIRE) != 0ull)
+        return fail(G2048_ERR_HIP, "a two-chain rollout's ordering ticket (%llu) did not arrive within the wait's bound "
+                                   "(%u polls of ~1 us): its chains ran unordered from there on, the engine's boards and "
+                                   "the rollout's outputs are undefined -- destroy the engine",
+                    __atomic_load_n(e->chain_err_host, __ATOMIC_ACQUIRE), e->chain_wait_polls);
+    return G2048_OK;
+}
+
+int poison(g2048_engine *e, const char *what)
+{
+    e->poisoned = 1;
+    snprintf(e->poison_msg, sizeof e->poison_msg, "%s; the engine is unusable from here on (a rollout was left half-done): destroy it", what);
+    return fail(G2048_ERR_HIP, "%s", e->poison_msg);
+}
+
 size_t action_size(int dtype)
 {
     switch (dtype) {
@@ -297,7 +238,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 13; }
+int g2048_abi_version(void) { return 14; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -396,6 +337,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipEventDestroy(e->join_event);
         if (e->chain_flags)
             (void)hipFree(e->chain_flags);
+        if (e->chain_err_host)
+            (void)hipHostFree(e->chain_err_host);
         if (e->st.rng)
             (void)hipFree(e->st.rng);
         if (e->scratch)
@@ -418,8 +361,8 @@ int g2048_destroy(g2048_engine *e)
 
 int g2048_seed(g2048_engine *e, uint64_t seed, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     e->seed = seed;
     e->t = 0;
     e->fresh = 1;
@@ -432,8 +375,8 @@ int g2048_seed(g2048_engine *e, uint64_t seed, void *stream)
 
 int g2048_set_last_records(g2048_engine *e, int enable, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     if (enable && !e->track_last) // records from before the pause would be stale: start from "none yet"
         G2048_HIP(hipMemsetAsync(e->st.last_record, 0, e->n * 16, static_cast<hipStream_t>(stream)));
@@ -448,7 +391,9 @@ int g2048_get_last_records(const g2048_engine *e)
 
 int g2048_get_clock(const g2048_engine *e, uint64_t *t)
 {
-    if (!e || !t)
+    if (int rc = usable(e))
+        return rc;
+    if (!t)
         return fail(G2048_ERR_INVALID, "NULL argument");
     *t = e->t;
     return G2048_OK;
@@ -456,8 +401,8 @@ int g2048_get_clock(const g2048_engine *e, uint64_t *t)
 
 int g2048_set_clock(g2048_engine *e, uint64_t t)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     e->t = t;
     e->fresh = 0;
     return G2048_OK;
@@ -467,16 +412,16 @@ uint64_t g2048_num_boards(const g2048_engine *e) { return e ? e->n : 0; }
 
 int g2048_set_illegal_move_reward(g2048_engine *e, float reward)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     e->illegal_reward = reward;
     return G2048_OK;
 }
 
 int g2048_set_max_tile(g2048_engine *e, int max_exp)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (max_exp < 0 || max_exp > 31)
         return fail(G2048_ERR_INVALID, "max_exp %d out of range 0..31", max_exp);
     e->max_exp = static_cast<uint32_t>(max_exp);
@@ -485,8 +430,8 @@ int g2048_set_max_tile(g2048_engine *e, int max_exp)
 
 int g2048_reset(g2048_engine *e, int new_transaction, uint32_t first_slot, const uint8_t *mask, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     if (new_transaction)
         e->t += 1;
@@ -501,8 +446,8 @@ int g2048_reset(g2048_engine *e, int new_transaction, uint32_t first_slot, const
 
 int g2048_step(g2048_engine *e, const g2048_step_io *io, int auto_reset, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (int rc = check_io(io))
         return rc;
     G2048_HIP(hipSetDevice(e->device));
@@ -580,6 +525,20 @@ static int ensure_side_chain(g2048_engine *e)
         G2048_HIP(hipMemset(e->chain_flags, 0, 256));
         G2048_HIP(hipStreamSynchronize(nullptr)); // (the fill is only enqueued, and not ordered against non-blocking streams)
     }
+    if (!e->chain_err_host) { // where a ticket wait that ran out reports (flag_wait_kernel)
+        void *host = nullptr, *dev = nullptr;
+        hipError_t err = hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (err != hipSuccess)
+            return fail(G2048_ERR_NOMEM, "hipHostMalloc(64) for the chains' error word failed: %s", hipGetErrorString(err));
+        err = hipHostGetDevicePointer(&dev, host, 0);
+        if (err != hipSuccess) {
+            (void)hipHostFree(host);
+            return fail(G2048_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(err));
+        }
+        std::memset(host, 0, 64);
+        e->chain_err_host = static_cast<unsigned long long *>(host);
+        e->chain_err_dev = static_cast<unsigned long long *>(dev);
+    }
     std::lock_guard<std::mutex> lock(g_side_mutex);
     SideChain *sc = g_side[e->device];
     if (!sc) {
@@ -601,10 +560,11 @@ static int ensure_side_chain(g2048_engine *e)
         }
         sc->priority = greatest;
         SideLauncher *w = &sc->launcher;
-        w->thread = std::thread([w] { w->run(); });
+        w->spin_us = g2048::side_spin_us_from_env(); // 200 us unless the caller opted into a longer window
+        w->start();
         // prime it: a thread's first HIP calls set up per-thread runtime state (tens of microseconds) -- here, not in
         // somebody's first two-chain rollout
-        unsigned long long *scratch_flag = e->chain_flags + 32;
+        unsigned long long *scratch_flag = e->chain_flags + 24; // (fork = 0 and join = 16 leave words 17..31 of the 256 bytes free)
         const int dev = e->device;
         hipStream_t side_stream = sc->stream;
         const uint64_t ticket = w->post([dev, scratch_flag, side_stream]() -> int {
@@ -629,14 +589,25 @@ static int ensure_side_chain(g2048_engine *e)
 
 int g2048_set_chains(g2048_engine *e, int chains)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (chains != 1 && chains != 2)
         return fail(G2048_ERR_INVALID, "chains must be 1 or 2 (got %d)", chains);
     if (chains == 2) {
         G2048_HIP(hipSetDevice(e->device));
         if (int rc = ensure_side_chain(e))
             return rc;
+        // The knobs of this form are read HERE, once (not per rollout): a test or a measurement sets the environment and
+        // calls g2048_set_chains(e, 2) again.
+        const char *v = std::getenv("G2048_TWO_CHAIN_MIN_STEPS");
+        const long forced = v ? std::atol(v) : 0l;
+        e->chain_min_steps = forced >= 2 ? static_cast<uint32_t>(forced) : 0u;
+        v = std::getenv("G2048_FLAG_WAIT_POLLS");
+        const long polls = v ? std::atol(v) : 0l;
+        e->chain_wait_polls = polls > 0 && polls < 0x7fffffffl ? static_cast<uint32_t>(polls) : g2048::kFlagWaitPolls;
+        e->chain_any_priority = std::getenv("G2048_CHAIN_ANY_PRIORITY") != nullptr;
+        v = std::getenv("G2048_CHAIN_SYNC");
+        e->chain_by_events = v && std::strcmp(v, "events") == 0;
     }
     e->chains = chains;
     return G2048_OK;
@@ -648,8 +619,8 @@ int g2048_get_chains_used(const g2048_engine *e) { return e ? e->last_rollout_ch
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (int rc = check_io(io))
         return rc;
     G2048_HIP(hipSetDevice(e->device));
@@ -659,14 +630,23 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     // ---- two chains: the batch is cut at a block boundary and each half gets its own stream and launch thread.
     //      Spawn-stream mode only (the numpy-RNG planes are indexed with the engine's board count), not while the
     //      caller captures a graph (another thread must not launch during a global capture), and only when both halves
-    //      are whole blocks of work.
+    //      are whole blocks of work.  A rollout can only be split when ALL its k_steps actions are supplied up front, and
+    //      the split only pays from kTwoChainMinSteps steps: a caller that steps one action at a time (ppo_train.py) never
+    //      gets here, whatever g2048_set_chains said.
     const uint32_t n = static_cast<uint32_t>(e->n);
     const uint32_t first_half = (n / 2u) & ~255u;
-    // (G2048_TWO_CHAIN_MIN_STEPS: measurement / test knob -- split every rollout of at least that many steps; read per
-    //  call, so a test can set it at any time)
-    const char *forced = e->chains == 2 ? std::getenv("G2048_TWO_CHAIN_MIN_STEPS") : nullptr;
-    const long forced_min_steps = forced ? std::atol(forced) : 0l;
     bool two = e->chains == 2 && e->side && !e->st.rng && first_half >= 256u && k_steps >= 2;
+    // warm: the side chain had work until recently; need: the rollout length from which the split pays right now
+    const bool warm = two && steady_now_ns() < e->side->busy_until_ns.load(std::memory_order_relaxed);
+    const uint32_t need = e->chain_min_steps ? e->chain_min_steps : warm ? kTwoChainMinSteps : kTwoChainColdMinSteps;
+    if (two && k_steps < need) {
+        // Too short to split.  A rollout within reach of the threshold still wakes a sleeping launcher, so that a loop of
+        // such rollouts finds it spinning when one of them qualifies; short ones (a step at a time) leave it asleep -- an
+        // idle core is not spent on a caller that cannot use the second chain.
+        if (k_steps >= kTwoChainMinSteps / 2u && e->side->launcher.sleeping.load())
+            e->side->launcher.nudge();
+        two = false;
+    }
     if (two) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) != hipSuccess) {
@@ -681,7 +661,7 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         // streams that share one run in submission order: the caller's wait for the join ticket could then sit in front of
         // the side launches it waits for.  Such a stream gets one chain.  (Streams of other priorities have their own
         // queues; one runtime call per rollout.)
-        if (s != nullptr && !std::getenv("G2048_CHAIN_ANY_PRIORITY")) { // (the knob: to measure what the rule avoids)
+        if (s != nullptr && !e->chain_any_priority) {
             int prio = 0;
             if (hipStreamGetPriority(s, &prio) != hipSuccess) {
                 (void)hipGetLastError();
@@ -690,15 +670,6 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
                 two = false;
             }
         }
-    }
-    if (two) {
-        const bool asleep = e->side->launcher.sleeping.load();
-        const bool warm = std::chrono::steady_clock::now() < e->side->busy_until; // (read without the lock: a heuristic)
-        const uint32_t need = forced_min_steps >= 2 ? static_cast<uint32_t>(forced_min_steps)
-                              : warm ? kTwoChainMinSteps : kTwoChainColdMinSteps;
-        if (asleep)
-            e->side->launcher.nudge(); // any rollout wakes the launcher: the next one finds it spinning
-        two = k_steps >= need;
     }
     e->last_rollout_chains = two ? 2 : 1;
     const uint64_t t0 = e->t;
@@ -715,12 +686,18 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     if (!two) {
         for (uint32_t j = 0; j < k_steps; ++j) {
             const g2048::StepArgs a = args_of(j);
+            hipError_t err;
             if (e->st.rng) {
-                G2048_HIP(g2048::launch_step_numpy(a, io->action_dtype, s));
-                if (a.boards_out)
-                    G2048_HIP(g2048::launch_export_boards(e->st.boards, a.n, a.boards_out, s));
+                err = g2048::launch_step_numpy(a, io->action_dtype, s);
+                if (err == hipSuccess && a.boards_out)
+                    err = g2048::launch_export_boards(e->st.boards, a.n, a.boards_out, s);
             } else {
-                G2048_HIP(g2048::launch_step(a, io->action_dtype, s));
+                err = g2048::launch_step(a, io->action_dtype, s);
+            }
+            if (err != hipSuccess) {
+                // steps 0 .. j-1 are enqueued and will run: the clock says so, and the caller gets the error
+                e->t = t0 + j;
+                return fail(G2048_ERR_HIP, "launch of step %u of %u failed: %s", j, k_steps, hipGetErrorString(err));
             }
         }
         return G2048_OK;
@@ -728,30 +705,40 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     // fork / join: the side stream starts where the caller's stream stands, and whatever the caller enqueues next runs
     // after both halves.  By tickets in device memory (flag_set_kernel / flag_wait_kernel) -- or, G2048_CHAIN_SYNC=events,
     // by HIP events (the portable form; ~30 us more latency per rollout on this runtime).
-    static const bool by_flags = [] {
-        const char *v = std::getenv("G2048_CHAIN_SYNC");
-        return !(v && std::strcmp(v, "events") == 0);
-    }();
+    const bool by_flags = !e->chain_by_events;
     SideChain *sc = e->side;
     std::lock_guard<std::mutex> side_in_use(sc->use); // (another engine of this device may be using the side chain)
     hipStream_t side_stream = sc->stream;
     const unsigned long long seq = ++e->chain_seq;
     unsigned long long *fork_flag = e->chain_flags, *join_flag = e->chain_flags + 16;
-    if (by_flags) {
-        G2048_HIP(g2048::launch_flag_set(fork_flag, seq, s)); // enqueued BEFORE the side thread can enqueue its wait
-    } else {
-        G2048_HIP(hipEventRecord(e->fork_event, s));
-        G2048_HIP(hipStreamWaitEvent(side_stream, e->fork_event, 0));
+    unsigned long long *err_word = e->chain_err_dev;
+    const uint32_t polls = e->chain_wait_polls;
+    {   // nothing has been launched yet: a failure here leaves the engine as it was
+        hipError_t err;
+        if (by_flags) {
+            err = g2048::launch_flag_set(fork_flag, seq, s); // enqueued BEFORE the side thread can enqueue its wait
+        } else {
+            err = hipEventRecord(e->fork_event, s);
+            if (err == hipSuccess)
+                err = hipStreamWaitEvent(side_stream, e->fork_event, 0);
+        }
+        if (err != hipSuccess) {
+            e->t = t0;
+            return fail(G2048_ERR_HIP, "cannot fork the two chains: %s", hipGetErrorString(err));
+        }
     }
     SideLauncher *w = &sc->launcher;
     const int dtype = io->action_dtype;
     // The caller's chain gets a HEAD START of one launch (~3.3 us of host time, about half a half-batch kernel): two
     // chains that start together run their load phases together, like one big kernel.
     hipError_t mine = g2048::launch_step(part_of(args_of(0), dtype, 0u, first_half), dtype, s);
-    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n, fork_flag, join_flag, seq, side_stream]() -> int {
-        if (hipSetDevice(e->device) != hipSuccess)
+    const uint64_t ticket = w->post([e, w, args_of, k_steps, dtype, first_half, n, fork_flag, join_flag, seq, side_stream, by_flags,
+                                     err_word, polls]() -> int {
+        if (hipSetDevice(e->device) != hipSuccess) {
+            snprintf(w->error, sizeof w->error, "the side launch thread could not select device %d", e->device);
             return G2048_ERR_HIP;
-        hipError_t err = by_flags ? g2048::launch_flag_wait(fork_flag, seq, side_stream) : hipSuccess;
+        }
+        hipError_t err = by_flags ? g2048::launch_flag_wait(fork_flag, seq, err_word, polls, side_stream) : hipSuccess;
         for (uint32_t j = 0; j < k_steps && err == hipSuccess; ++j)
             err = g2048::launch_step(part_of(args_of(j), dtype, first_half, n - first_half), dtype, side_stream);
         // the join ticket goes out even after a failed launch: the caller's stream must never wait for a ticket nobody sets
@@ -768,25 +755,31 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
     for (uint32_t j = 1; j < k_steps && mine == hipSuccess; ++j)
         mine = g2048::launch_step(part_of(args_of(j), dtype, 0u, first_half), dtype, s);
     const int theirs = w->wait(ticket); // (the side thread has ISSUED its launches; nothing waits for the device here)
-    if (theirs != G2048_OK)
-        return fail(theirs, "%s", w->error);
-    if (by_flags)
-        G2048_HIP(g2048::launch_flag_wait(join_flag, seq, s));
-    else
-        G2048_HIP(hipStreamWaitEvent(s, e->join_event, 0));
+    // The JOIN is enqueued whatever happened above: side-stream kernels that were launched may still be writing the
+    // engine's and the caller's buffers, and whatever the caller enqueues next on `stream` must come after them.
+    hipError_t join = by_flags ? g2048::launch_flag_wait(join_flag, seq, err_word, polls, s) : hipStreamWaitEvent(s, e->join_event, 0);
     // the side stream has ~k_steps half-batch kernels ahead of it (they are only enqueued): warm until they are done + a bit
-    sc->busy_until = std::chrono::steady_clock::now() +
-                         std::chrono::microseconds(static_cast<long>(k_steps * (4.0e-6 * n + 0.5) + kSideWarmWindowUs));
-    if (mine != hipSuccess)
-        return fail(G2048_ERR_HIP, "launch failed: %s", hipGetErrorString(mine));
+    sc->busy_until_ns.store(steady_now_ns() + static_cast<int64_t>((k_steps * (4.0e-6 * n + 0.5) + kSideWarmWindowUs) * 1000.0),
+                            std::memory_order_relaxed);
+    if (theirs != G2048_OK || mine != hipSuccess || join != hipSuccess) {
+        // some launches of the rollout are enqueued and some are not: the halves of the batch no longer stand at the same
+        // step, and nothing the caller could do would repair that
+        char what[256];
+        if (theirs != G2048_OK)
+            snprintf(what, sizeof what, "two-chain rollout: %s", w->error);
+        else
+            snprintf(what, sizeof what, "two-chain rollout: %s failed: %s", mine != hipSuccess ? "a launch on the caller's stream" : "the join",
+                     hipGetErrorString(mine != hipSuccess ? mine : join));
+        return poison(e, what);
+    }
     return G2048_OK;
 }
 
 int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                         void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (int rc = check_io(io))
         return rc;
     if (io->terminal_boards || io->obs || io->boards_out)
@@ -807,8 +800,8 @@ int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *
 
 int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (k_steps == 0)
         return G2048_OK;
     if (e->st.rng)
@@ -826,7 +819,9 @@ int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream)
 int g2048_move(g2048_engine *e, const void *actions, int32_t action_dtype, int trial, int32_t *score_out,
                uint8_t *legal_out, void *stream)
 {
-    if (!e || !actions)
+    if (int rc = usable(e))
+        return rc;
+    if (!actions)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (action_dtype < G2048_ACT_U8 || action_dtype > G2048_ACT_I64)
         return fail(G2048_ERR_INVALID, "g2048_move needs an action buffer (dtype %d)", action_dtype);
@@ -840,8 +835,8 @@ int g2048_move(g2048_engine *e, const void *actions, int32_t action_dtype, int t
 
 int g2048_query(const g2048_engine *e, uint8_t *isend_out, uint8_t *highest_out, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(g2048::launch_query(e->st.boards, static_cast<uint32_t>(e->n), e->max_exp, isend_out, highest_out,
                                   static_cast<hipStream_t>(stream)));
@@ -850,7 +845,9 @@ int g2048_query(const g2048_engine *e, uint8_t *isend_out, uint8_t *highest_out,
 
 int g2048_legal_actions(const g2048_engine *e, uint8_t *mask_out, void *stream)
 {
-    if (!e || !mask_out)
+    if (int rc = usable(e))
+        return rc;
+    if (!mask_out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(g2048::launch_legal_mask(e->st.boards, static_cast<uint32_t>(e->n), mask_out, static_cast<hipStream_t>(stream)));
@@ -859,8 +856,8 @@ int g2048_legal_actions(const g2048_engine *e, uint8_t *mask_out, void *stream)
 
 int g2048_add_tile(g2048_engine *e, uint32_t slot, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     e->fresh = 0;
     const g2048::StepArgs a = make_args(e, nullptr, 0);
@@ -873,7 +870,9 @@ int g2048_add_tile(g2048_engine *e, uint32_t slot, void *stream)
 
 int g2048_fill_random_actions(const g2048_engine *e, uint64_t t_first, uint32_t k_steps, uint8_t *out, void *stream)
 {
-    if (!e || !out)
+    if (int rc = usable(e))
+        return rc;
+    if (!out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(g2048::launch_fill_actions(out, static_cast<uint32_t>(e->n), static_cast<uint32_t>(e->board_offset),
@@ -884,7 +883,9 @@ int g2048_fill_random_actions(const g2048_engine *e, uint64_t t_first, uint32_t 
 
 int g2048_onehot(const g2048_engine *e, void *out, int32_t obs_dtype, void *stream)
 {
-    if (!e || !out)
+    if (int rc = usable(e))
+        return rc;
+    if (!out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (obs_dtype < G2048_OBS_U8 || obs_dtype > G2048_OBS_F32)
         return fail(G2048_ERR_INVALID, "unknown obs_dtype %d", obs_dtype);
@@ -898,7 +899,9 @@ int g2048_onehot(const g2048_engine *e, void *out, int32_t obs_dtype, void *stre
 
 static int copy_out(const g2048_engine *e, void *dst, const void *src, size_t bytes, void *stream)
 {
-    if (!e || !dst)
+    if (int rc = usable(e))
+        return rc;
+    if (!dst)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
@@ -908,7 +911,9 @@ static int copy_out(const g2048_engine *e, void *dst, const void *src, size_t by
 
 static int copy_in(g2048_engine *e, void *dst, const void *src, size_t bytes, void *stream)
 {
-    if (!e || !src)
+    if (int rc = usable(e))
+        return rc;
+    if (!src)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     G2048_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
@@ -1034,7 +1039,9 @@ static int wait_done(g2048_engine *e, unsigned long long want, hipStream_t s)
 
 int g2048_host_io_map(g2048_engine *e, g2048_host_io *out)
 {
-    if (!e || !out)
+    if (int rc = usable(e))
+        return rc;
+    if (!out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     if (int rc = ensure_host_io(e))
@@ -1045,8 +1052,8 @@ int g2048_host_io_map(g2048_engine *e, g2048_host_io *out)
 
 int g2048_step_host(g2048_engine *e, int auto_reset, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (!e->host_base)
         return fail(G2048_ERR_INVALID, "call g2048_host_io_map first (the actions are read from its buffer)");
     G2048_HIP(hipSetDevice(e->device));
@@ -1081,8 +1088,8 @@ int g2048_step_host(g2048_engine *e, int auto_reset, void *stream)
 
 int g2048_fetch_host(g2048_engine *e, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (!e->host_base)
         return fail(G2048_ERR_INVALID, "call g2048_host_io_map first");
     G2048_HIP(hipSetDevice(e->device));
@@ -1097,7 +1104,9 @@ int g2048_fetch_host(g2048_engine *e, void *stream)
 
 int g2048_stream_signal(g2048_engine *e, void *stream, uint64_t *ticket)
 {
-    if (!e || !ticket)
+    if (int rc = usable(e))
+        return rc;
+    if (!ticket)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1113,8 +1122,8 @@ int g2048_stream_signal(g2048_engine *e, void *stream, uint64_t *ticket)
 
 int g2048_stream_wait(g2048_engine *e, uint64_t ticket, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     if (!e->done_host || ticket == 0 || ticket > e->done_count)
         return fail(G2048_ERR_INVALID, "ticket %llu was not issued by g2048_stream_signal on this engine",
                     (unsigned long long)ticket);
@@ -1209,7 +1218,9 @@ static int enter_device_of(DeviceScope &scope, const void *const *bufs, int n_bu
 int g2048_get_boards(const g2048_engine *ce, uint8_t *buf, void *stream)
 {
     g2048_engine *e = const_cast<g2048_engine *>(ce);
-    if (!e || !buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1228,7 +1239,9 @@ int g2048_get_boards(const g2048_engine *ce, uint8_t *buf, void *stream)
 
 int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream)
 {
-    if (!e || !buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1252,7 +1265,9 @@ int g2048_set_boards(g2048_engine *e, const uint8_t *buf, void *stream)
 int g2048_get_scores(const g2048_engine *ce, int32_t *buf, void *stream)
 {
     g2048_engine *e = const_cast<g2048_engine *>(ce);
-    if (!e || !buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1271,7 +1286,9 @@ int g2048_get_scores(const g2048_engine *ce, int32_t *buf, void *stream)
 
 int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
 {
-    if (!e || !buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1298,7 +1315,9 @@ int g2048_set_scores(g2048_engine *e, const int32_t *buf, void *stream)
 int g2048_get_last_scores(const g2048_engine *ce, int32_t *buf, void *stream)
 {
     g2048_engine *e = const_cast<g2048_engine *>(ce);
-    if (!e || !buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (int rc = need_last_records(e, "g2048_get_last_scores"))
         return rc;
@@ -1322,7 +1341,9 @@ void *g2048_last_records_ptr(const g2048_engine *e) { return e && e->track_last 
 
 int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
 {
-    if (!e || !out)
+    if (int rc = usable(e))
+        return rc;
+    if (!out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1345,7 +1366,9 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
 static int stats_async(const g2048_engine *e, g2048_stats *device_out, bool returns_only, void *stream)
 {
     static_assert(sizeof(g2048_stats) == sizeof(g2048::StatsOut), "g2048_stats and the kernel's StatsOut must share one layout");
-    if (!e || !device_out)
+    if (int rc = usable(e))
+        return rc;
+    if (!device_out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (!is_device_ptr(device_out))
         return fail(G2048_ERR_INVALID, "the asynchronous statistics need a DEVICE buffer (use g2048_episode_stats for a host struct)");
@@ -1383,8 +1406,8 @@ static int ensure_numpy_rng(g2048_engine *e)
 
 int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
 {
-    if (!e)
-        return fail(G2048_ERR_INVALID, "engine is NULL");
+    if (int rc = usable(e))
+        return rc;
     G2048_HIP(hipSetDevice(e->device));
     if (!planes) { // back to the spawn stream
         if (e->st.rng)
@@ -1443,7 +1466,9 @@ uint64_t g2048_state_bytes(const g2048_engine *e)
 
 int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream)
 {
-    if (!e || !host_buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!host_buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     StateHeader h{kStateMagic, e->n, e->seed, e->board_offset, e->t, e->fresh, e->max_exp, e->illegal_reward,
                   (e->st.rng ? 1u : 0u) | (e->track_last ? 0u : 2u)}; // flags: 1 = numpy-RNG planes follow, 2 = no terminal records
@@ -1458,7 +1483,9 @@ int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream)
 
 int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, void *stream)
 {
-    if (!e || !host_buf)
+    if (int rc = usable(e))
+        return rc;
+    if (!host_buf)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (blob_bytes < sizeof(StateHeader))
         return fail(G2048_ERR_INVALID, "state blob is too short (%llu bytes)", (unsigned long long)blob_bytes);
@@ -1642,7 +1669,9 @@ int g2048_comm_destroy(g2048_comm *c)
 int g2048_allgather_returns(const g2048_engine *ce, g2048_comm *c, int32_t *out, void *stream)
 {
     g2048_engine *e = const_cast<g2048_engine *>(ce);
-    if (!e || !c || !out)
+    if (int rc = usable(e))
+        return rc;
+    if (!c || !out)
         return fail(G2048_ERR_INVALID, "NULL argument");
     if (c->device != e->device)
         return fail(G2048_ERR_INVALID, "communicator is on device %d, engine on device %d", c->device, e->device);

@@ -245,16 +245,23 @@ G2048_DEV uint32_t count_empty(const Board &bd)
     return g2048_popc(z80(bd.r[0]) | (z80(bd.r[1]) >> 1) | (z80(bd.r[2]) >> 2) | (z80(bd.r[3]) >> 3));
 }
 
-// game2048_env.py:166-176 with the injected spawn word w: value 2 (exp 1) if (w & 0xffff) <= 58982
-// else 4 (exp 2); position = k-th empty cell in row-major order, k = (w * n_empty) >> 32.
-// `enable` (all-ones / 0) gates the write.  Returns the number of empty cells BEFORE the spawn.
-// `is2` = "the new tile is a 2", i.e. (w & 0xffff) <= 58982 (passed in where the caller needs it as well).
-G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable, bool is2)
+// The spawn word w on a board with n empty cells (game2048_env.py:166-176), read off the 64-bit product p = w * n:
+//   position  k = p >> 32: the k-th empty cell in row-major order (= floor(u * n), u = w / 2^32);
+//   value     2 (exponent 1) if (uint32_t)p <= kTwoThreshold else 4, i.e. frac(u * n) < 0.9 (:168) -- the part of the
+//             word the position did not use: uniform and independent of k up to the word's resolution, so P(2) is
+//             within n / 2^32 < 4e-9 of the reference's 0.9.
+constexpr uint32_t kTwoThreshold = 3865470566u; // r / 2^32 < 0.9  <=>  r <= 3865470566
+
+// `enable` (all-ones / 0) gates the write.  Returns the number of empty cells BEFORE the spawn; `is2` = "the new
+// tile is a 2" (the callers that keep the score deficit need it as well).
+G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable, bool &is2)
 {
     const uint32_t z0 = z80(bd.r[0]), z1 = z80(bd.r[1]), z2 = z80(bd.r[2]), z3 = z80(bd.r[3]);
     const uint32_t c0 = g2048_popc(z0), c1 = c0 + g2048_popc(z1), c2 = c1 + g2048_popc(z2),
                    n = c2 + g2048_popc(z3);
-    const uint32_t k = g2048_mulhi(w, n);
+    const uint64_t p = static_cast<uint64_t>(w) * n;
+    const uint32_t k = static_cast<uint32_t>(p >> 32);
+    is2 = static_cast<uint32_t>(p) <= kTwoThreshold;
     // row of the k-th empty cell: g_i = all-ones when k >= c_i (nested: g2 implies g1 implies g0)
     const uint32_t g0 = (uint32_t)((int32_t)(c0 - 1u - k) >> 31), g1 = (uint32_t)((int32_t)(c1 - 1u - k) >> 31),
                    g2 = (uint32_t)((int32_t)(c2 - 1u - k) >> 31);
@@ -278,8 +285,14 @@ G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable, bool is2)
 
 G2048_DEV uint32_t add_tile(Board &bd, uint32_t w, uint32_t enable = 0xffffffffu)
 {
-    return add_tile(bd, w, enable, (w & 0xffffu) <= 58982u);
+    bool is2;
+    return add_tile(bd, w, enable, is2);
 }
+
+// The two spawns of a reset (game2048_env.py:108-109) on the empty board: the first word meets 16 empty cells
+// (k = w1 >> 28, fraction = w1 << 4), the second 15.
+G2048_DEV bool fresh_is_four_16(uint32_t w1) { return (w1 << 4) > kTwoThreshold; }
+G2048_DEV bool fresh_is_four_15(uint32_t w2) { return w2 * 15u > kTwoThreshold; }
 
 // game2048_env.py:102-111: empty board + two spawns from words w1, w2.
 G2048_DEV Board fresh_board(uint32_t w1, uint32_t w2)
@@ -287,8 +300,8 @@ G2048_DEV Board fresh_board(uint32_t w1, uint32_t w2)
     const uint32_t p1 = w1 >> 28;                  // (w1 * 16) >> 32: cell of the first tile
     const uint32_t k2 = g2048_mulhi(w2, 15u);
     const uint32_t p2 = k2 + (k2 >= p1 ? 1u : 0u); // k2-th empty cell, skipping p1
-    const uint32_t e1 = ((w1 & 0xffffu) <= 58982u) ? 1u : 2u;
-    const uint32_t e2 = ((w2 & 0xffffu) <= 58982u) ? 1u : 2u;
+    const uint32_t e1 = fresh_is_four_16(w1) ? 2u : 1u;
+    const uint32_t e2 = fresh_is_four_15(w2) ? 2u : 1u;
     // place each exponent in a 64-bit half (cells 0-7 / 8-15) with one 64-bit shift
     const uint64_t x1 = (uint64_t)e1 << (8u * (p1 & 7u)), x2 = (uint64_t)e2 << (8u * (p2 & 7u));
     const uint32_t h1 = lanemask_bit0(p1 >> 3), h2 = lanemask_bit0(p2 >> 3); // upper half?
@@ -462,7 +475,7 @@ G2048_DEV void record_update(Board &raw, const Board &cells, uint32_t inc_spread
 G2048_DEV Board fresh_record(uint32_t w1, uint32_t w2)
 {
     Board bd = fresh_board(w1, w2);
-    const uint32_t fours = (((w1 & 0xffffu) <= 58982u) ? 0u : 1u) + (((w2 & 0xffffu) <= 58982u) ? 0u : 1u);
+    const uint32_t fours = (fresh_is_four_16(w1) ? 1u : 0u) + (fresh_is_four_15(w2) ? 1u : 0u);
     // d = 4 -> bit 2 of d = bit 7 of byte 8; d = 8 -> bit 3 of d = bit 5 of byte 9
     bd.r[2] |= fours == 1u ? 0x80u : (fours == 2u ? 0x2000u : 0u);
     return bd;
@@ -477,8 +490,8 @@ G2048_DEV Board fresh_record_lut(uint32_t w1, uint32_t w2, const Tables &tb)
     const uint32_t p1 = w1 >> 28;                  // (w1 * 16) >> 32: cell of the first tile
     const uint32_t k2 = g2048_mulhi(w2, 15u);
     const uint32_t p2 = k2 + (k2 >= p1 ? 1u : 0u); // k2-th empty cell, skipping p1
-    const uint32_t s1 = ((w1 & 0xffffu) > 58982u) ? 1u : 0u; // 1: the tile is a 4 (exponent 2 = 1 << 1)
-    const uint32_t s2 = ((w2 & 0xffffu) > 58982u) ? 1u : 0u;
+    const uint32_t s1 = fresh_is_four_16(w1) ? 1u : 0u; // 1: the tile is a 4 (exponent 2 = 1 << 1)
+    const uint32_t s2 = fresh_is_four_15(w2) ? 1u : 0u;
     const Board a = tb.onehot_cell(p1), b = tb.onehot_cell(p2);
     const uint32_t fours = s1 + s2;
     Board bd;
@@ -571,9 +584,9 @@ G2048_DEV StepOut play_record(Board &rec, uint32_t action, const Words &w, uint3
     o.legal = move_sel(cells, tb.move_sel(action), o.gain);        // :85 (illegal: board unchanged, gain 0)
     const uint32_t lm = lanemask(o.legal);
     o.legal_mask = lm;
-    const bool is2 = (w.w[0] & 0xffffu) <= 58982u;                 // :168 the spawn's value
     // :88 add_tile needs an empty cell; a board that changed always has one (a full board can only
     // change by merging).  After an illegal move nothing is spawned (:91-95).
+    bool is2;                                                      // :168 the spawn's value
     const uint32_t n_empty = add_tile(cells, w.w[0], lm, is2);
     // :89 isend(): the board is full after the spawn exactly when it had one empty cell before it
     bool end = false;

@@ -108,7 +108,10 @@ hipError_t launch_fetch(const uint4 *records, uint32_t n, uint4 *cells_out, int3
 hipError_t launch_signal(unsigned long long *done_seq, unsigned long long done_value, hipStream_t s);
 // stream-to-stream ordering by a ticket in device memory (two-chain rollouts): set behind the work it stands for, wait (bounded) before what depends on it
 hipError_t launch_flag_set(unsigned long long *flag, unsigned long long value, hipStream_t s);
-hipError_t launch_flag_wait(const unsigned long long *flag, unsigned long long value, hipStream_t s);
+// `timed_out`: host-visible word that receives `value` when the wait gives up after `max_polls` polls (~1 us each)
+hipError_t launch_flag_wait(const unsigned long long *flag, unsigned long long value, unsigned long long *timed_out,
+                            uint32_t max_polls, hipStream_t s);
+constexpr uint32_t kFlagWaitPolls = 1u << 26;
 hipError_t launch_canonicalize(uint4 *boards, uint4 *next_boards, uint8_t *actions, uint32_t n, uint8_t *sym_out,
                                hipStream_t s);
 

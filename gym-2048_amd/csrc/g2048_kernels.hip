@@ -19,6 +19,8 @@
 #include "g2048_device.h"
 #include "g2048_pcg64.h"
 
+#include <atomic>
+
 
 namespace g2048 {
 
@@ -323,19 +325,23 @@ static_assert(sizeof(WaveTables) * (kBlock / 64) + sizeof(uint4) * kBlock + kObs
 // the device granted it, 0 where it did not (a part with less LDS, a runtime that refuses) -- the kernel is then merely
 // not occupancy-capped, instead of every observation-writing launch failing.
 template <class Kernel>
-static uint32_t obs_pad_for(Kernel kernel, signed char (&state)[64])
+static uint32_t obs_pad_for(Kernel kernel, std::atomic<signed char> (&state)[64])
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         dev = 0;
-    if (state[dev] == 0) {
+    // (launches come from several threads -- two chains, LocalShards: the per-device answer is an atomic; two threads that
+    //  both find it unset both ask the runtime, which is idempotent)
+    signed char known = state[dev].load(std::memory_order_acquire);
+    if (known == 0) {
         const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    static_cast<int>(kObsOccupancyPad));
         if (err != hipSuccess)
             (void)hipGetLastError(); // not sticky: the launch below goes ahead without the pad
-        state[dev] = err == hipSuccess ? 1 : -1;
+        known = err == hipSuccess ? 1 : -1;
+        state[dev].store(known, std::memory_order_release);
     }
-    return state[dev] > 0 ? kObsOccupancyPad : 0u;
+    return known > 0 ? kObsOccupancyPad : 0u;
 }
 
 template <int OBS, bool FULL>
@@ -402,23 +408,29 @@ __global__ void __launch_bounds__(64) signal_kernel(unsigned long long *done_seq
 // work it stands for, in stream order), flag_wait_kernel on the other stream spins until the ticket is there (agent-scope
 // acquire) and the kernels behind it follow in stream order.  An event record + hipStreamWaitEvent pair costs this
 // runtime ~15 us of latency per crossing; the flag pair a few us (tools/chain_fixed_cost.py).  The wait is BOUNDED
-// (2^25 polls, about a minute -- longer than any work a caller could reasonably have queued ahead of the ticket): a
-// ticket that never comes -- a failed launch on the other side -- must not hang the device for good.
+// (2^26 polls of ~1 us, one to two minutes -- longer than any work a caller could reasonably have queued ahead of the
+// ticket): a ticket that never comes must not hang the device for good.  A wait that runs out is LOUD: it publishes the
+// ticket it gave up on in `timed_out` -- a word of pinned, coherent host memory the library checks at the entry of every
+// call on the engine, which then fails with G2048_ERR_HIP -- because the kernels behind it run unordered against the
+// other chain from there on.
 __global__ void __launch_bounds__(64) flag_set_kernel(unsigned long long *flag, unsigned long long value)
 {
     if (threadIdx.x == 0)
         __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void __launch_bounds__(64) flag_wait_kernel(const unsigned long long *flag, unsigned long long value)
+__global__ void __launch_bounds__(64) flag_wait_kernel(const unsigned long long *flag, unsigned long long value,
+                                                       unsigned long long *timed_out, uint32_t max_polls)
 {
     if (threadIdx.x != 0)
         return;
-    for (uint32_t spin = 0; spin < (1u << 25); ++spin) {
+    for (uint32_t spin = 0; spin < max_polls; ++spin) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value)
             return;
         __builtin_amdgcn_s_sleep(16); // ~1 us between polls
     }
+    if (timed_out)
+        __hip_atomic_store(timed_out, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------- step
@@ -1353,7 +1365,7 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     do {                                                                                                                \
         uint32_t pad = 0u;                                                                                              \
         if (OBS) {                                                                                                      \
-            static signed char pad_state[64] = {};                                                                      \
+            static std::atomic<signed char> pad_state[64] = {};                                                                      \
             pad = obs_pad_for(&step_kernel<ACT, FULL, STD, OBS>, pad_state);                                            \
         }                                                                                                               \
         hipLaunchKernelGGL((step_kernel<ACT, FULL, STD, OBS>), g, b, pad, s, a.st.boards,                               \
@@ -1648,9 +1660,10 @@ hipError_t launch_flag_set(unsigned long long *flag, unsigned long long value, h
     return hipGetLastError();
 }
 
-hipError_t launch_flag_wait(const unsigned long long *flag, unsigned long long value, hipStream_t s)
+hipError_t launch_flag_wait(const unsigned long long *flag, unsigned long long value, unsigned long long *timed_out,
+                            uint32_t max_polls, hipStream_t s)
 {
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, flag, value);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, flag, value, timed_out, max_polls);
     return hipGetLastError();
 }
 

@@ -42,8 +42,11 @@
  *  board global board index = board_offset + local index (so results do not depend on how the
  *        batch is sharded over GPUs);
  *  slot  0 for the step's spawn, then the two spawns of a reset that follows in the same transaction.
- *  A spawn with word w on a board with n empty cells puts 2 if (w & 0xffff) <= 58982 else 4 into
- *  the k-th empty cell (row-major), k = (w * n) >> 32   (game2048_env.py:166-176).
+ *  A spawn with word w on a board with n empty cells is read off the 64-bit product p = w * n: the new tile goes
+ *  into the k-th empty cell (row-major), k = p >> 32, and is a 2 if (uint32_t)p <= 3865470566 else a 4
+ *  (game2048_env.py:166-176: `random() < 0.9` with random() = frac(w * n / 2^32), the part of the word the position
+ *  did not use -- P(2) within n / 2^32 < 4e-9 of the reference's 0.9, value and position independent to the same
+ *  precision; ABI <= 13 compared the word's low 16 bits, P(2) = 0.900009).
  */
 #ifndef G2048_H
 #define G2048_H

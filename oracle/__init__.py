@@ -48,6 +48,8 @@ def load():
     lib.g2048o_philox4x32_10.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     lib.g2048o_spawn_word.argtypes = [u64, u64, u32, u32]
     lib.g2048o_spawn_word.restype = u32
+    lib.g2048o_spawn_value.argtypes = [u32, u32]
+    lib.g2048o_spawn_value.restype = C.c_int64
     lib.g2048o_random_action.argtypes = [u64, u64, u32]
     lib.g2048o_random_action.restype = C.c_uint8
     lib.g2048o_shift.argtypes = [i64p, i64p]

@@ -25,7 +25,13 @@ import numpy as np
 M0, M1 = 0xD2511F53, 0xCD9E8D57  # Philox4x32 multipliers
 W0, W1 = 0x9E3779B9, 0xBB67AE85  # Weyl key increments
 MASK32 = 0xFFFFFFFF
-TWO_THRESHOLD = 58982  # (w & 0xffff) / 65536 < 0.9  <=>  (w & 0xffff) <= 58982
+TWO_THRESHOLD = 3865470566  # r / 2**32 < 0.9  <=>  r <= 3865470566, r = (w * n_empty) mod 2**32 (SURVEY 8c's constant)
+
+
+def spawn_fraction(w: int, n_empty: int) -> float:
+    """random() of the injected stream: the fraction of w * n_empty / 2**32 that the position k = (w * n_empty) >> 32
+    leaves over -- uniform on [0, 1), independent of k up to the word's resolution (oracle/g2048_oracle.h)."""
+    return ((w * n_empty) & MASK32) / 4294967296.0
 
 
 def philox4x32_10(ctr, key):
@@ -84,10 +90,12 @@ class SpawnStream:
     The reference's ``add_tile`` (game2048_env.py:166-176) calls ``random()`` once and then
     ``shuffle(positions)`` once.  Both are served from ONE 32-bit word of the spawn stream:
 
-    * ``random()``  -> ``(w & 0xffff) / 65536.0`` (the reference itself compares it with 0.9);
     * ``shuffle()`` -> moves the k-th empty cell of ``env.Matrix`` (row-major,
       ``k = (w * n_empty) >> 32``) to the front of the list, so the reference's "first empty
-      cell in shuffled order" (game2048_env.py:171-175) is that cell.
+      cell in shuffled order" (game2048_env.py:171-175) is that cell;
+    * ``random()``  -> ``((w * n_empty) mod 2**32) / 2**32``, the fraction that position left over
+      (the reference itself compares it with 0.9; the board does not change between the two calls,
+      game2048_env.py:168-170, so ``n_empty`` is the same in both).
 
     The driver calls ``begin_step()`` immediately before every ``env.step()``; ``env.reset()``
     without a seed simply continues with the next slots of the current transaction.
@@ -110,7 +118,7 @@ class SpawnStream:
 
     def random(self):
         self._w = spawn_word(self.seed, self.t, self.board, self.slot)
-        return (self._w & 0xFFFF) / 65536.0
+        return spawn_fraction(self._w, int((self.env.Matrix == 0).sum()))
 
     def shuffle(self, positions):
         w, self._w = self._w, None
@@ -203,8 +211,8 @@ class RefEnv:
     def add_tile(self):
         w = spawn_word(self.seed, self.t, self.board, self.slot)
         self.slot += 1
-        value = 2 if (w & 0xFFFF) / 65536.0 < 0.9 else 4
         empties = [i for i in range(16) if self.M[i] == 0]
+        value = 2 if spawn_fraction(w, len(empties)) < 0.9 else 4
         assert empties, "No empty cell found"
         self.M[empties[(w * len(empties)) >> 32]] = value
 

@@ -52,10 +52,13 @@ uint8_t g2048o_random_action(uint64_t seed, uint64_t t, uint32_t board)
 }
 
 /* game2048_env.py:168  val = 2 if self.np_random.random() < 0.9 else 4
- * with random() := (w & 0xffff) / 65536.0 -- evaluated here in double exactly as Python would. */
-int64_t g2048o_spawn_value(uint32_t w)
+ * with random() := frac(w * n_empty / 2^32) = ((w * n_empty) mod 2^32) / 2^32 -- what is left of the word once the
+ * position k = floor(w * n_empty / 2^32) has been taken out of it -- evaluated here in double exactly as Python would
+ * (a 32-bit integer over 2^32 is exact in a double).  P(2) is within n_empty / 2^32 < 4e-9 of the reference's 0.9, and
+ * value and position are independent to the same precision. */
+int64_t g2048o_spawn_value(uint32_t w, uint32_t n_empty)
 {
-    double u = (double)(w & 0xffffu) / 65536.0;
+    double u = (double)(uint32_t)((uint64_t)w * n_empty) / 4294967296.0;
     return u < 0.9 ? 2 : 4;
 }
 
@@ -154,10 +157,10 @@ int g2048o_isend(const int64_t M[16], int64_t max_tile)
 /* game2048_env.py:166-176 */
 int g2048o_add_tile(int64_t M[16], uint32_t w)
 {
-    int64_t val = g2048o_spawn_value(w);                /* :168 */
     uint32_t n_empty = 0;
     for (int i = 0; i < 16; ++i)
         n_empty += (M[i] == 0);
+    int64_t val = g2048o_spawn_value(w, n_empty);       /* :168 (drawn before the position, used after it) */
     if (n_empty == 0)
         return -1;                                      /* :176 assert False */
     uint32_t k = g2048o_spawn_rank(w, n_empty);         /* :169-170 injected shuffle */

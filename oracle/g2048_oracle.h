@@ -43,10 +43,13 @@ uint32_t g2048o_spawn_word(uint64_t seed, uint64_t t, uint32_t board, uint32_t s
  * action(seed, t, board) = word(seed, t, board, 3) >> 30. */
 uint8_t g2048o_random_action(uint64_t seed, uint64_t t, uint32_t board);
 
-/* The two quantities add_tile needs from one 32-bit word (game2048_env.py:168-175):
- *   value:    2 if (w & 0xffff) / 65536.0 < 0.9 else 4     (<=> (w & 0xffff) <= 58982)
- *   position: the k-th empty cell in row-major order, k = (w * n_empty) >> 32            */
-int64_t g2048o_spawn_value(uint32_t w);
+/* The two quantities add_tile needs from one 32-bit word w on a board with n_empty empty cells
+ * (game2048_env.py:168-175), read off the 64-bit product p = w * n_empty:
+ *   position: the k-th empty cell in row-major order, k = p >> 32  (= floor(u * n_empty), u = w / 2^32)
+ *   value:    2 if (p mod 2^32) / 2^32 < 0.9 else 4                (<=> (uint32_t)p <= 3865470566)
+ * i.e. the fraction of u * n_empty that the position did not use: uniform on [0, 1) and independent of k up to
+ * the word's resolution, so P(2) is within n_empty / 2^32 < 4e-9 of the reference's 0.9. */
+int64_t g2048o_spawn_value(uint32_t w, uint32_t n_empty);
 uint32_t g2048o_spawn_rank(uint32_t w, uint32_t n_empty);
 
 /* ------------------------------------------------ reference functions, on int64 tile values */

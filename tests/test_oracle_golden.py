@@ -45,11 +45,25 @@ def test_spawn_word_layout(oracle_lib):
 
 
 def test_spawn_value_threshold(oracle_lib):
-    # random() := (w & 0xffff) / 65536 < 0.9  <=>  (w & 0xffff) <= 58982
-    for low in (0, 58981, 58982, 58983, 65535):
-        want = 2 if low / 65536.0 < 0.9 else 4
-        assert oracle_lib.g2048o_spawn_value(0xabcd0000 | low) == want
-        assert (2 if low <= cpu_ref.TWO_THRESHOLD else 4) == want
+    # random() := ((w * n) mod 2^32) / 2^32 < 0.9  <=>  (w * n) mod 2^32 <= 3865470566   (n = empty cells)
+    T = cpu_ref.TWO_THRESHOLD
+    assert T / 4294967296.0 < 0.9 <= (T + 1) / 4294967296.0
+    rng = np.random.default_rng(5)
+    words = [0, 1, T - 1, T, T + 1, 0xffffffff] + [int(x) for x in rng.integers(0, 1 << 32, 200)]
+    for n in range(1, 17):
+        for w in words + [(T + d) // n for d in (-n, 0, 1, n, 2 * n)]:
+            w &= 0xffffffff
+            r = (w * n) & 0xffffffff
+            want = 2 if r / 4294967296.0 < 0.9 else 4
+            assert oracle_lib.g2048o_spawn_value(w, n) == want
+            assert (2 if r <= T else 4) == want
+            assert (2 if cpu_ref.spawn_fraction(w, n) < 0.9 else 4) == want
+    # the marginal probability of a 2, exactly: for odd n the map w -> w * n mod 2^32 is a bijection; an even n = 2^a * m
+    # maps 2^a words onto every multiple of 2^a
+    for n in range(1, 17):
+        a = (n & -n).bit_length() - 1
+        p2 = ((T >> a) + 1) * (1 << a) / 4294967296.0
+        assert abs(p2 - 0.9) < 4e-9
 
 
 def test_shift_exhaustive(oracle_lib):
