@@ -96,9 +96,11 @@ class Batched2048:
         self._boards_view = None
         if not last_records:
             self.set_last_records(False)
-        # two-chain rollouts (g2048_set_chains): on by default where they pay -- half a million boards and more, spawn-stream mode
+        # two-chain rollouts (g2048_set_chains) are OPT-IN: they start a launch thread and a high-priority stream per
+        # device and only ever fire for rollouts of >= 12 steps whose actions are all supplied up front -- which a
+        # trainer that steps one action at a time (ppo_train.py) never issues
         if chains is None:
-            chains = 2 if (self.n_envs >= (1 << 19) and rng == "philox") else 1
+            chains = 1
         if chains != 1:
             self.set_chains(chains)
         if self.rng_mode == "numpy":
@@ -151,8 +153,10 @@ class Batched2048:
         """1: a rollout is one chain of launches on the current stream.  2: ``rollout`` cuts the batch in two and runs
         the halves as two chains -- the lower half on the current stream from this thread, the upper half on an
         engine-owned side stream from an engine-owned launch thread -- forked from and joined back into the current
-        stream inside every call; bit-identical results, 12-15 % less time per step at 2^19 .. 2^20 boards
-        (``g2048_set_chains``)."""
+        stream inside every call; bit-identical results, 12-15 % less time per step at 2^19 .. 2^20 boards for rollouts of
+        a few hundred steps (``g2048_set_chains``).  Opt-in (the default is 1): only a ``rollout`` of >= 12 steps with all
+        its actions supplied up front can be split at all; the launch thread spins for ``G2048_SIDE_SPIN_US`` (default
+        200 us, read when the device's side chain is created) after a job before it sleeps."""
         check(self._lib.g2048_set_chains(self._h, int(chains)))
 
     @property
@@ -679,9 +683,13 @@ def parse_stats(raw) -> dict:
     if not isinstance(raw, (bytes, bytearray)):
         raw = np.ascontiguousarray(raw, dtype=np.uint8).tobytes()
     st = Stats.from_buffer_copy(bytes(raw))
-    return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count,
-                last_score_sum=st.last_score_sum, last_score_max=st.last_score_max, max_exp=st.max_exp,
-                mean_last_score=(st.last_score_sum / st.last_count) if st.last_count else 0.0,
+    # last_score_max == -1: the terminal records were not read (a returns-only summary, or an engine that does not keep
+    # them) -- the last_* keys are then None, not a measured 0
+    known = st.last_score_max >= 0
+    return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count if known else None,
+                last_score_sum=st.last_score_sum if known else None, last_score_max=st.last_score_max if known else None,
+                max_exp=st.max_exp,
+                mean_last_score=((st.last_score_sum / st.last_count) if st.last_count else 0.0) if known else None,
                 highest_hist=[int(x) for x in st.highest_hist],
                 return_sum=st.return_sum,      # exact: final merge scores of ALL finished episodes
                 mean_episode_score=(st.return_sum / st.episodes) if st.episodes else 0.0)

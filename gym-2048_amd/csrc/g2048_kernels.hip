@@ -1305,8 +1305,11 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
 
 // block f: field f of every partial -> the matching member of *out (fields 4 and 5 are maxima, the rest sums mod 2^64)
 // (the returns-only flavour launches the first kStatsScalars blocks only; block 5 then also clears the histogram)
+// last_known: the terminal records were read (the full flavour on an engine that keeps them).  Otherwise last_count and
+// last_score_sum are 0 and last_score_max is -1 -- "not computed", which no score can be -- so that a reader of the struct
+// (parse_stats, a peer rank behind an all-gather) cannot mistake the zeros for a measured mean of 0.
 __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long long *partials, uint32_t n_partials,
-                                                             StatsOut *out)
+                                                             StatsOut *out, bool last_known)
 {
     __shared__ unsigned long long s_v[kBlock];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
@@ -1335,7 +1338,7 @@ __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long
     case 1: out->illegal_ends = v; break;
     case 2: out->last_count = v; break;
     case 3: out->last_score_sum = v; break;
-    case 4: out->last_score_max = static_cast<int>(v); break;
+    case 4: out->last_score_max = last_known ? static_cast<int>(v) : -1; break;
     case 5: out->max_exp = static_cast<unsigned int>(v); break;
     case 6: out->return_sum = static_cast<long long>(v); break;
     default: out->highest_hist[f - kStatsScalars] = static_cast<unsigned int>(v); break;
@@ -1573,10 +1576,11 @@ hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *p
         blocks = 1; // n == 0: one block writes an all-zero partial
     if (returns_only) {
         hipLaunchKernelGGL(stats_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
-        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsScalars), dim3(kBlock), 0, s, partials, blocks, dev_out);
+        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsScalars), dim3(kBlock), 0, s, partials, blocks, dev_out, false);
     } else {
         hipLaunchKernelGGL(stats_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
-        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out);
+        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out,
+                           st.last_record != nullptr);
     }
     return hipGetLastError();
 }

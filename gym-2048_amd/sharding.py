@@ -90,11 +90,17 @@ def merge_stats(rows) -> dict:
     from .batched import parse_stats
     parts = [parse_stats(r) for r in rows]
     tot = dict(episodes=sum(p["episodes"] for p in parts), illegal_ends=sum(p["illegal_ends"] for p in parts),
-               last_count=sum(p["last_count"] for p in parts), last_score_sum=sum(p["last_score_sum"] for p in parts),
-               last_score_max=max(p["last_score_max"] for p in parts), max_exp=max(p["max_exp"] for p in parts),
+               max_exp=max(p["max_exp"] for p in parts),
                highest_hist=[sum(col) for col in zip(*(p["highest_hist"] for p in parts))],
                return_sum=sum(p["return_sum"] for p in parts))
-    tot["mean_last_score"] = tot["last_score_sum"] / tot["last_count"] if tot["last_count"] else 0.0
+    # the last_* numbers exist only where the terminal records were read (parse_stats: None for a returns-only summary
+    # or an engine that does not keep them): one such row and the global figure is unknown, not a smaller sum
+    if all(p["last_count"] is not None for p in parts):
+        tot.update(last_count=sum(p["last_count"] for p in parts), last_score_sum=sum(p["last_score_sum"] for p in parts),
+                   last_score_max=max(p["last_score_max"] for p in parts))
+        tot["mean_last_score"] = tot["last_score_sum"] / tot["last_count"] if tot["last_count"] else 0.0
+    else:
+        tot.update(last_count=None, last_score_sum=None, last_score_max=None, mean_last_score=None)
     tot["mean_episode_score"] = tot["return_sum"] / tot["episodes"] if tot["episodes"] else 0.0
     return tot
 

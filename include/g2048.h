@@ -119,7 +119,9 @@ typedef struct {
     uint64_t last_count;     /* boards that have finished at least one episode */
     int64_t last_score_sum;  /* sum over those boards of the final merge score (game2048_env.py:86) of their MOST
                               * RECENT finished episode (the engine keeps one terminal record per board) */
-    int32_t last_score_max;  /* best of those */
+    int32_t last_score_max;  /* best of those; -1 = NOT COMPUTED: last_count / last_score_sum / last_score_max are only filled by
+                              * g2048_episode_stats[_async] on an engine that keeps terminal records (g2048_set_last_records);
+                              * g2048_returns_summary_async never reads them (ABI <= 13 wrote zeros there) */
     uint32_t max_exp;        /* highest exponent currently on any board */
     uint32_t highest_hist[32]; /* highest_hist[k] = boards whose highest tile (game2048_env.py:190-192) is 2^k
                                 * right now (k = 0: empty board) -- what ppo_train.py:77-81 tallies */

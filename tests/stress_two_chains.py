@@ -46,10 +46,12 @@ def run(seconds=120.0, seed=0, n_threads=3):
                         counts["engines"] += 1
                     for _ in range(int(rs.integers(3, 40))):
                         k = int(rs.integers(1, 90))
-                        if rs.random() < 0.7:
-                            os.environ["G2048_TWO_CHAIN_MIN_STEPS"] = "2"    # (process-wide, read per call: the other
-                        else:                                                  #  workers see it too -- any value is legal)
-                            os.environ.pop("G2048_TWO_CHAIN_MIN_STEPS", None)
+                        with lock:   # the knob is process-wide and g2048_set_chains is what reads it (once, not per rollout)
+                            if rs.random() < 0.7:
+                                os.environ["G2048_TWO_CHAIN_MIN_STEPS"] = "2"
+                            else:
+                                os.environ.pop("G2048_TWO_CHAIN_MIN_STEPS", None)
+                            two.set_chains(2)
                         r2 = torch.zeros((k, n), dtype=torch.float32, device=two.device)
                         r1 = torch.zeros((k, n), dtype=torch.float32, device=one.device)
                         d2 = torch.zeros((k, n), dtype=torch.uint8, device=two.device)

@@ -77,8 +77,9 @@ def test_bench_configuration_2p20_rollout_buffers_without_terminal_records(torch
     st = eng.episode_stats()
     assert st["episodes"] == int(ora.ep_count.sum()) > n // 2
     assert st["return_sum"] == ora.return_sum == ora.finished_return_sum > 0
-    assert st["last_count"] == st["last_score_sum"] == st["last_score_max"] == 0       # not kept
+    assert st["last_count"] is st["last_score_sum"] is st["last_score_max"] is st["mean_last_score"] is None   # not kept: unknown, not 0
     ro = parse_stats(eng.episode_stats_device(returns_only=True))
+    assert ro["last_count"] is None and ro["mean_last_score"] is None
     assert (ro["episodes"], ro["illegal_ends"], ro["return_sum"]) == (st["episodes"], st["illegal_ends"], st["return_sum"])
     for call in (eng.get_last_scores, eng.last_scores, eng.last_records):
         with pytest.raises(G2048Error, match="terminal records"):

@@ -391,3 +391,26 @@ def test_np_random_attribute_without_gymnasium():
         other.np_random = np.random.Generator(np.random.MT19937(1))
     env.close()
     assert env._io is None
+
+
+def test_stats_rows_without_terminal_records_read_as_unknown_not_zero():
+    """g2048_returns_summary_async (and an engine that keeps no terminal records) leaves last_score_max = -1: parse_stats
+    turns the last_* keys into None, and merge_stats refuses to average a known shard with an unknown one."""
+    from gym2048_amd._lib import Stats
+    from gym2048_amd.batched import parse_stats
+    from gym2048_amd.sharding import merge_stats
+    full = Stats(episodes=10, illegal_ends=1, last_count=4, last_score_sum=400, last_score_max=150, max_exp=7, return_sum=900)
+    summary = Stats(episodes=6, illegal_ends=0, last_count=0, last_score_sum=0, last_score_max=-1, max_exp=5, return_sum=300)
+    a, b = parse_stats(bytes(full)), parse_stats(bytes(summary))
+    assert (a["last_count"], a["last_score_sum"], a["last_score_max"], a["mean_last_score"]) == (4, 400, 150, 100.0)
+    assert b["last_count"] is b["last_score_sum"] is b["last_score_max"] is b["mean_last_score"] is None
+    assert (b["episodes"], b["return_sum"], b["mean_episode_score"]) == (6, 300, 50.0)
+    both = merge_stats([bytes(full), bytes(summary)])
+    assert (both["episodes"], both["illegal_ends"], both["return_sum"], both["max_exp"]) == (16, 1, 1200, 7)
+    assert both["mean_episode_score"] == 75.0
+    assert both["last_count"] is both["mean_last_score"] is both["last_score_max"] is None
+    known = merge_stats([bytes(full), bytes(full)])
+    assert (known["last_count"], known["last_score_sum"], known["last_score_max"], known["mean_last_score"]) == (8, 800, 150, 100.0)
+    # a board that finished with score 0 is a measured 0, not "unknown"
+    zero = parse_stats(bytes(Stats(episodes=1, last_count=1, last_score_sum=0, last_score_max=0)))
+    assert zero["last_count"] == 1 and zero["mean_last_score"] == 0.0
