@@ -21,7 +21,19 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-def register(entry_point: str = "gym2048_amd:Game2048Env"):
+def register(entry_point="gym2048_amd:Game2048Env"):
     """Register ``'2048-v0'`` with gymnasium like the reference's ``env/__init__.py:1-6``."""
     from gymnasium.envs.registration import register as _register
     _register(id=ENV_ID, entry_point=entry_point)
+
+
+# env/__init__.py:1-6 registers '2048-v0' when the package is imported, and its callers rely on that
+# (ppo_train.py:102 `gym.make("2048-v0", render_mode="rgb_array")`, :123 `make_vec_env("2048-v0", ...)`): so does this
+# package, whenever gymnasium is importable.  Without gymnasium there is nothing to register with.
+try:
+    import gymnasium as _gymnasium  # noqa: F401
+except ImportError:
+    _gymnasium = None
+if _gymnasium is not None:
+    register()
+del _gymnasium
