@@ -53,6 +53,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ALGO_BYTES_PER_STEP = 38          # board in 16 + action 1 + board out 16 + reward 4 + terminated 1
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED = 42
+REF_PORT_RATIO = 3.53            # oracle.cpu_ref.RefEnv steps/s over the reference's Game2048Env.step steps/s
 AGE_STEPS = 64                    # fused steps that bring a freshly reset batch to the steady-state mix of episode ages
 
 
@@ -314,13 +315,14 @@ def main():
     # off (g2048_set_last_records: one sparse 16-byte store per finished episode less; extras.with_last_records has the
     # same launch train with them on); --gather full ships every board's last return and keeps them.
     if args.chains is None:
-        # Two chains by default.  Exception: short rollouts in a process that holds an RCCL communicator -- behind a
-        # two-chain 20-step train the once-per-rollout exchange (summary kernels + all-gather) takes 80-140 us in three
-        # runs out of four instead of 27 us (forced one-rank group, profiles/r04_ab_forced_dist_chains.txt): with two
-        # threads launching, the calling thread reaches the exchange (~100 us of host work) about when the device finishes
-        # a 20-step train, so the host's latency shows; from a few hundred steps on two chains win again (K = 400: 8.09 vs
-        # 8.94 us per step including the exchange).
-        args.chains = 1 if (dist_on and backend == "nccl" and K < 200) else 2
+        # The launch form is decided by K ALONE, the same for every N, so that the points of a scaling curve are the same
+        # thing measured at different N: one chain (one whole-batch launch per step) below 200 steps, two chains from 200.
+        # Below 200 steps two chains buy nothing measurable (the driver's K = 20: 9.34 vs 9.36 us per step, BENCH_r04) and
+        # behind an RCCL communicator they delay the once-per-rollout exchange (profiles/r04_ab_forced_dist_chains.txt);
+        # at K = 1 000 they are 13 % faster per step.
+        args.chains = 1 if K < 200 else 2
+    if args.chains == 2:
+        os.environ.setdefault("G2048_SIDE_SPIN_US", "2000")   # opt into the long spin window of the side launch thread (default 200 us)
     keep_last = args.gather == "full"
     eng = Batched2048(B, device=local_rank, seed=SEED, board_offset=shard.offset, last_records=keep_last, chains=args.chains)
     eng.reset()
@@ -405,45 +407,58 @@ def main():
                 break
             (wplan if left > 4e-3 else wshort).run()     # memory clocks: per-step launches that stream; short trains at the
             torch.cuda.synchronize()                     # end, so that every rank stops within ~0.2 ms of the deadline
+    def timed_region():
+        """ONE timed region with the contract's brackets: barrier + synchronize | exactly K steps [+ the exchange] | the
+        host learns that the device is done.  Returns (wall seconds, launch-train ms, collective ms, gathered rows, cost
+        of the synchronize() after the poll in us)."""
+        barrier()                                            # opening bracket: barrier + synchronize
+        ev0.record()                                         # on the (idle) launch stream: start of the launch train
+        t0 = time.perf_counter()
+        plan.run()                                           # g2048_rollout: EXACTLY K step launches
+        ev1.record()
+        # the path's only exchange: once per rollout, N > 1 only.  Enqueued behind the last step launch; at N > 1 it is
+        # also the closing barrier (an all-gather completes on no rank before every rank has contributed)
+        rows = gather_returns() if dist_on else None
+        ev2.record()
+        # closing bracket: [collective +] the host learns that the device is done.  By default through the library's
+        # completion word (g2048_stream_signal / g2048_stream_wait: a one-wave kernel behind everything above publishes a
+        # ticket to pinned host memory with a system-scope release, the host polls it) -- the same guarantee as a stream
+        # synchronisation, a few us sooner (tools/ubench/tail_probe.hip); the contract's synchronize() follows and finds
+        # nothing left to wait for (its cost is reported, not timed).  G2048_BENCH_CLOSE=sync times synchronize() itself.
+        if close_by_poll:
+            eng.stream_wait(eng.stream_signal())
+            wall = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            after_us = (time.perf_counter() - t0 - wall) * 1e6
+        else:
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            after_us = 0.0
+        return wall, ev0.elapsed_time(ev1), (ev1.elapsed_time(ev2) if dist_on else 0.0), rows, after_us
+
     for wp in wplans:                                    # the W untimed warm-up steps of the benchmarked engine
         wp.run()
-    barrier()                                            # opening bracket: barrier + synchronize
-    ev0.record()                                         # on the (idle) launch stream: start of the launch train
-    t0 = time.perf_counter()
-    plan.run()                                           # g2048_rollout: EXACTLY K step launches
-    ev1.record()
-    # the path's only exchange: once per rollout, N > 1 only.  Enqueued behind the last step launch; at N > 1 it is
-    # also the closing barrier (an all-gather completes on no rank before every rank has contributed)
-    gathered = gather_returns() if dist_on else None
-    ev2.record()
-    # closing bracket: [collective +] the host learns that the device is done.  By default through the library's
-    # completion word (g2048_stream_signal / g2048_stream_wait: a one-wave kernel behind everything above publishes a
-    # ticket to pinned host memory with a system-scope release, the host polls it) -- the same guarantee as a stream
-    # synchronisation, a few us sooner (tools/ubench/tail_probe.hip); the contract's synchronize() follows and finds
-    # nothing left to wait for (its cost is reported, not timed).  G2048_BENCH_CLOSE=sync times synchronize() itself.
-    if close_by_poll:
-        eng.stream_wait(eng.stream_signal())
-        elapsed = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        sync_after_us = (time.perf_counter() - t0 - elapsed) * 1e6
-    else:
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        sync_after_us = 0.0
+    elapsed, kernel_region_ms, collective_ms, gathered, sync_after_us = timed_region()   # THE timed region: `value`
     timed_chains = eng.chains_used
+    # five further regions of the same K steps with the same brackets (not `value`: how much one 200 us sample moves)
+    repeats = []
+    for _ in range(5 if K <= 2000 else 0):
+        r_wall, r_train, r_coll, _, _ = timed_region()
+        repeats.append((r_wall, r_train, r_coll))
     if scratch is not None:
         scratch.close()
         del scratch, sa, sr, st_, wplan, wshort
-    kernel_region_ms = ev0.elapsed_time(ev1)
-    collective_ms = ev1.elapsed_time(ev2) if dist_on else 0.0
 
-    tmax = torch.tensor([elapsed, kernel_region_ms, collective_ms], dtype=torch.float64,
+    tmax = torch.tensor([elapsed, kernel_region_ms, collective_ms] + [x for r in repeats for x in r], dtype=torch.float64,
                         device=dev if backend == "nccl" else "cpu")
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_region_ms, collective_ms = float(tmax[0]), float(tmax[1]), float(tmax[2])
+    repeats = [tuple(float(x) for x in tmax[3 + 3 * i: 6 + 3 * i]) for i in range(len(repeats))]
+    gathered_rows = None
     if gathered is not None:
         assert gathered.numel() == (B * world if args.gather == "full" else stats_bytes * world)
+        gathered_rows = int(gathered.shape[0]) if args.gather == "summary" else int(gathered.numel() // B)
 
     # sanity inside the bench: the rollout really happened (episodes finished, rewards written)
     stats = eng.episode_stats()
@@ -455,61 +470,46 @@ def main():
     working_set_mib = (B * 16 * 2 + B * 6) / 2**20
 
     eff_chains = timed_chains    # what g2048_rollout did in the timed region (a two-chain engine splits only rollouts that pay)
+    wall_us_per_step = elapsed * 1e6 / K
     out = {
         "metric": ("env-steps/sec at batch=2^20 per MI355X" if B == (1 << 20) else f"env-steps/sec at batch={B} per MI355X"), "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"batch={B} envs per GPU, random-policy rollout, int8 boards (BASELINE configs[2])",
                    "boards_per_gpu": B, "global_boards": B * world, "seed": SEED,
-                   "state": f"reset, then {AGE_STEPS} fused steps (steady-state mix of episode ages, SURVEY 8d's >= 50 "
-                            f"warm-up steps), then the W warm-up steps",
-                   "device_warmup": (f"{args.device_warmup} s of rollouts on a SCRATCH engine (fused + per-step launches) "
-                                     f"before anything is measured") if args.device_warmup > 0 else "none",
-                   "path": (("TWO step_kernel launches per env-step, one per half of the batch, as two chains on two streams "
-                             "issued by two host threads (g2048_set_chains(2): fork / join on the launch stream inside "
-                             "g2048_rollout; bit-identical to one chain), " if eff_chains == 2 else
-                             "one step_kernel launch per env-step (g2048_rollout), ") +
+                   "state": f"reset + {AGE_STEPS} fused steps (steady-state episode ages) + the W warm-up steps",
+                   "device_warmup_s": args.device_warmup,
+                   "path": (("two step_kernel launches per env-step (half batches, two chains on two streams, g2048_set_chains(2)), "
+                             if eff_chains == 2 else "one step_kernel launch per env-step (g2048_rollout), ") +
                             "actions/reward/terminated in [K][B] HBM rollout buffers, auto-reset fused"),
-                   "chains": eff_chains,
-                   "chains_note": (f"engine set to {eng.chains} chains; g2048_rollout splits a rollout only when that pays: from 12 steps while "
-                                   f"the device's side chain is warm (work within the last 50 ms: here the scratch engine's warm-up, "
-                                   f"which shares it), from 64 steps when it is cold; `chains` is what the timed rollout did "
-                                   f"(g2048_get_chains_used; DESIGN.md 5.1a, profiles/r04_v_chain_fixed_cost.txt)"),
-                   "episode_bookkeeping": ("per-wavefront counters + exact return sum (g2048_stats.return_sum); per-board "
-                                           "terminal records " + ("ON (--gather full reads them)" if keep_last else
-                                                                  "OFF (g2048_set_last_records(0): not needed by the summary exchange; "
-                                                                  "extras.with_last_records times the same train with them on)")),
-                   "collective": (f"none per step; one all-gather per rollout of the "
-                                  + (f"per-rank episodic-return summaries (g2048_stats, {stats_bytes} B each)" if args.gather == "summary" else "per-board episodic returns (int32[B] each)")
+                   "chains": eff_chains, "chains_requested": eng.chains,
+                   "chains_rule": "by K alone, for every N: 1 below 200 steps, 2 from 200 (DESIGN.md 5.1a); --chains overrides",
+                   "episode_bookkeeping": "per-wavefront counters + exact return sum; per-board terminal records " + ("on" if keep_last else "off"),
+                   # what the process group really was: a reader of a scaling curve can see that N ranks met
+                   "backend": (backend if dist_on else None),
+                   "pg_world_size": (dist.get_world_size() if dist_on else 1),
+                   "gathered_rows": gathered_rows,
+                   "collective": ((f"one all-gather per rollout of the per-rank return summaries (g2048_stats, {stats_bytes} B each)"
+                                   if args.gather == "summary" else "one all-gather per rollout of the per-board episodic returns (int32[B] each)")
                                   if dist_on else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
+                     # the same fraction from the one WALL-CLOCK number of the line (ms_per_step: host tail included)
+                     "frac_wall": ALGO_BYTES_PER_STEP * B / (wall_us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_provenance": traffic_prov,
                      "kernel": "g2048::step_kernel<1, true, true, false>", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
-                     "launch_us": launch_us,
-                     "launches_per_step": eff_chains,
-                     "launch_us_note": ("time per ENV-STEP of the whole batch = HIP-event time of the region / K: with two chains "
-                                        "a step is two half-batch launches (2^19 boards each at the default size) that run "
-                                        "CONCURRENTLY on two streams, so a kernel trace shows half-batch kernels whose individual "
-                                        "durations (~7-8 us) overlap; `achieved` is the algorithmic bytes of a whole step over the "
-                                        "step time.  extras.single_chain is the one-launch-per-step form of the same engine "
-                                        "(its launch time IS a kernel duration: compare that one with profiles/*kernel_stats.csv)")
-                                       if eff_chains == 2 else "HIP-event time of the region / K = one kernel per step",
-                     "issue_bound_note": "the step kernel saturates integer VALU issue before it saturates HBM: a compute-only "
-                                         "copy of it takes 105.9 us of a 114.6-117.7 us launch at 2^24 boards and 7.8 of 10.2 us "
-                                         "at 2^20, a memory-only copy 105.2 / 7.65 us (tools/ubench/r3_probe.hip part A, "
-                                         "profiles/r03_h_probe_2p24_a.txt, r03_d_probe_2p20.txt; DESIGN.md 5.1)",
-                     "note": (f"the {working_set_mib:.0f} MiB of board records touched per launch sit in the 256 MiB "
-                              "Infinity Cache at this batch size, so this is a cache-resident figure; "
-                              "extras.streaming_2p24 is the run that streams HBM") if B <= (1 << 22) else None},
+                     "launch_us": launch_us, "launches_per_step": eff_chains,
+                     "basis": "achieved = 38 B x boards / (HIP-event time of the K-step region / K); frac_wall uses ms_per_step",
+                     "notes": "DESIGN.md 5.1: cache-resident at 2^20 (extras.streaming_2p24 streams HBM); issue-bound before HBM-bound"},
         "timing": {"launch_train_us": kernel_region_ms * 1e3, "collective_us": collective_ms * 1e3,
                    "host_tail_us": elapsed * 1e6 - (kernel_region_ms + collective_ms) * 1e3,
-                   "closing": ("completion word polled by the host (g2048_stream_signal / g2048_stream_wait), then "
-                               "torch.cuda.synchronize()" if close_by_poll else "torch.cuda.synchronize()"),
+                   "closing": "poll" if close_by_poll else "synchronize",
                    "synchronize_after_poll_us": sync_after_us,
-                   "note": "max over ranks; wall = launch train (K step launches, HIP events) + collective (statistics "
-                           "kernel + all-gather, HIP events; 0 at N = 1) + host tail (launch-to-start latency and "
-                           "end-to-host-visible latency of the closing bracket)"},
+                   # five further K-step regions with the same brackets, right behind the timed one (max over ranks):
+                   # wall us per region, and their launch trains -- `value` stays the FIRST region
+                   "k_region_repeats_us": [r[0] * 1e6 for r in repeats],
+                   "k_region_repeats_launch_train_us": [r[1] * 1e3 for r in repeats],
+                   "k_region_first_us": elapsed * 1e6},
         "episodes_finished": int(stats["episodes"]), "return_sum": int(stats["return_sum"]),
         "mean_episode_score": stats["mean_episode_score"],        # exact: over ALL finished episodes of this rank's shard
     }
@@ -521,9 +521,7 @@ def main():
     if gathered is not None and args.gather == "summary":
         g = merge_stats(gathered)
         out["global_returns"] = {"episodes": g["episodes"], "illegal_ends": g["illegal_ends"], "return_sum": g["return_sum"],
-                                 "mean_episode_score": g["mean_episode_score"],
-                                 "note": "from the all-gathered per-rank summaries: every finished episode of every rank since "
-                                         "the reset (g2048_stats.return_sum is exact)"}
+                                 "mean_episode_score": g["mean_episode_score"]}
 
     if rank == 0 and world == 1 and not args.no_extras and not force_dist:
         extras = {}
@@ -589,6 +587,36 @@ def main():
                 extras["single_chain"] = {"error": str(exc)}
             finally:
                 eng.set_chains(2)
+        # (a2a') ... and when the timed engine ran as ONE chain (K < 200): the same engine as TWO chains over a 200-step
+        #        rollout (own buffers), the form `python bench.py` (K = 1 000) times -- best of 3
+        if eng.chains == 1:
+            try:
+                os.environ.setdefault("G2048_SIDE_SPIN_US", "2000")
+                eng.set_chains(2)
+                kk = 200
+                a2 = eng.random_actions(kk)
+                r2 = torch.zeros((kk, B), dtype=torch.float32, device=dev)
+                t2 = torch.zeros((kk, B), dtype=torch.uint8, device=dev)
+                tplan = eng.prepare_rollout(a2, reward=r2, terminated=t2)
+                tplan.run()
+                best = None
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    tplan.run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3 / kk
+                    best = us if best is None else min(best, us)
+                extras["two_chains_k200"] = {"us_per_step": best, "steps_per_s": B / (best * 1e-6), "steps": kk,
+                                             "chains_used": eng.chains_used,
+                                             "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * B / (best * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                del a2, r2, t2, tplan
+            except Exception as exc:  # pragma: no cover
+                extras["two_chains_k200"] = {"error": str(exc)}
+            finally:
+                eng.set_chains(1)
         # (a2b) the timed launch train on an engine that KEEPS the per-board terminal records (the library's default):
         #       what g2048_get_last_scores / --gather full cost the step
         try:
@@ -642,6 +670,44 @@ def main():
             del obs, oplan
         except Exception as exc:  # pragma: no cover
             extras["step_with_obs_u8"] = {"error": str(exc)}
+        # (a4) BASELINE configs[1]: 65 536 boards on one GPU, the same kernel, one chain; 200-launch trains over [200][65536]
+        #      buffers, best of 3 (SURVEY 8d "Config 2").  256 workgroups = one per CU: the launch is one latency chain, and
+        #      one host thread issues a launch every ~3 us -- this size is launch-bound, not HBM-bound
+        try:
+            ns, ks = 1 << 16, 200
+            small = Batched2048(ns, device=local_rank, seed=SEED, last_records=keep_last, chains=1)
+            small.reset()
+            small.rollout_random(AGE_STEPS)
+            sa_ = small.random_actions(ks)
+            sr_ = torch.zeros((ks, ns), dtype=torch.float32, device=dev)
+            st2 = torch.zeros((ks, ns), dtype=torch.uint8, device=dev)
+            splan = small.prepare_rollout(sa_, reward=sr_, terminated=st2)
+            splan.run()
+            runs = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                splan.run()
+                e1.record()
+                torch.cuda.synchronize()
+                runs.append(e0.elapsed_time(e1) * 1e3 / ks)
+            us = min(runs)
+            fplan = small.prepare_rollout(sa_, reward=sr_, terminated=st2, fused=True)
+            fplan.run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            fplan.run()
+            e1.record()
+            torch.cuda.synchronize()
+            extras["batch_65536"] = {"boards": ns, "launches": ks, "launch_us": us, "launch_us_runs": runs, "steps_per_s": ns / (us * 1e-6),
+                                     "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * ns / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                     "fused_rollout_with_io_steps_per_s": ks * ns / (e0.elapsed_time(e1) * 1e-3)}
+            small.close()
+            del sa_, sr_, st2, splan, fplan
+        except Exception as exc:  # pragma: no cover
+            extras["batch_65536"] = {"error": str(exc)}
         # (b) a batch that does not fit L2 + Infinity Cache: 2^24 boards (256 MiB of records).  Every buffer
         #     is written once before timing (first touch), 40 ms of untimed warm-up rollouts, best of 4 timed ones.
         del reward, terminated, actions
@@ -726,11 +792,21 @@ def main():
                 "launch_us": sc["launch_us"], "achieved": ALGO_BYTES_PER_STEP * B / (sc["launch_us"] * 1e-6) / 1e9,
                 "frac": sc["frac_of_hbm_peak"], "launches": sc["launches"],
                 "kernel_trace_avg_us": (out["roofline"].get("traffic_provenance") or {}).get("kernel_trace_avg_us")}
+        elif eff_chains == 1:
+            out["roofline"]["one_launch_per_step"] = {
+                "launch_us": launch_us, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "launches": K,
+                "kernel_trace_avg_us": (out["roofline"].get("traffic_provenance") or {}).get("kernel_trace_avg_us")}
         # (c) CPU legs (rank 0, N = 1 only per the contract; cheap enough to always show at N = 1)
         if world == 1:
             ge.build()
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-            extras["python_port_steps_per_s_1core"] = python_port_rate()
+            port = python_port_rate()
+            extras["python_port_steps_per_s_1core"] = port
+            # the reference itself cannot travel to this box: its rate is estimated from the Python port's, measured here, by
+            # the port / reference ratio measured in the build container (tests/golden/VALIDATION.txt: 3.4-3.7)
+            out["cpu_baseline"]["reference_estimate"] = {"value": port / REF_PORT_RATIO, "unit": "env-steps/s", "cores": 1,
+                                                         "basis": f"oracle.cpu_ref.RefEnv on 1 core of this box / {REF_PORT_RATIO} "
+                                                                  "(RefEnv / reference Game2048Env.step, both 1 core, build container)"}
 
     # The JSON line must be the LAST thing on stdout.  RCCL prints a version banner through C stdio, which a pipe only
     # flushes at exit -- after Python's own buffer -- and under torch.distributed.run every rank shares one stdout: so

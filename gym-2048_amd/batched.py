@@ -452,7 +452,7 @@ class Batched2048:
         """The same reduction as ``episode_stats`` left ON THE DEVICE: a ``uint8 [sizeof(g2048_stats)]`` tensor
         holding the C struct, enqueued on the current stream without a host sync (what a multi-GPU job
         all-gathers once per rollout; decode with ``parse_stats``).  ``returns_only``: only ``episodes``, ``illegal_ends``
-        and the exact ``return_sum`` (everything else zero) -- the terminal records are not read, no histogram."""
+        and the exact ``return_sum`` (histogram zero, ``last_*`` not computed: ``parse_stats`` gives None) -- the terminal records are not read."""
         nbytes = C.sizeof(Stats)
         if out is None:
             out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)

@@ -388,6 +388,48 @@ def test_two_chain_rollout_on_whatever_stream_the_caller_brings(torch_cuda):
     ref.close()
 
 
+def test_two_chain_ticket_that_does_not_arrive_in_time_is_loud(torch_cuda, monkeypatch):
+    """The ticket waits of a two-chain rollout are bounded, and a wait that runs out must not pass silently (its chain
+    then runs unordered against the other one): flag_wait_kernel reports through a pinned host word and EVERY later call
+    on the engine fails with G2048_ERR_HIP.  Provoked with a tiny bound (G2048_FLAG_WAIT_POLLS, read by g2048_set_chains)
+    and a caller's stream that is busy for tens of milliseconds in front of the fork ticket."""
+    torch = torch_cuda
+    import time
+    from gym2048_amd._lib import G2048Error
+    from gym2048_amd.batched import Batched2048
+    monkeypatch.setenv("G2048_TWO_CHAIN_MIN_STEPS", "2")
+    n, k = 4096, 8
+    rew = torch.zeros((k, n), dtype=torch.float32, device="cuda")
+    # a healthy engine first: the same rollout with the default bound is fine
+    ok = Batched2048(n, seed=3, chains=2)
+    ok.reset()
+    ok.rollout(k, reward=rew)
+    torch.cuda.synchronize()
+    assert ok.chains_used == 2 and ok.episode_stats()["episodes"] >= 0
+    ok.close()
+    # how long does torch's spin kernel take per million cycles on this box?  (aim at ~60 ms in front of the ticket)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(1_000_000)
+    torch.cuda.synchronize()
+    per_million = max(time.perf_counter() - t0, 1e-5)
+    cycles = int(min(0.06 / per_million, 400.0) * 1_000_000)
+    monkeypatch.setenv("G2048_FLAG_WAIT_POLLS", "300")           # ~0.3-1 ms
+    eng = Batched2048(n, seed=3, chains=2)
+    eng.reset()
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(cycles)                                # the fork ticket is queued behind this
+        eng.rollout(k, reward=rew)                               # the call itself cannot know yet
+    assert eng.chains_used == 2
+    torch.cuda.synchronize()
+    for call in (lambda: eng.step(None), eng.get_boards, eng.episode_stats, lambda: eng.rollout(k, reward=rew), eng.reset):
+        with pytest.raises(G2048Error, match="ordering ticket"):
+            call()
+    eng.close()                                                  # destroying it is what is left to do, and works
+
+
 def test_rollout_writes_terminal_boards(torch_cuda):
     """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
     episode and holds the board the episode ended on."""

@@ -49,25 +49,32 @@ def test_full_batch_2p20_random_policy_vs_oracle(torch_cuda):
     assert st["episodes"] == int(ora.ep_count.sum()) > n
 
 
-def test_bench_configuration_2p20_rollout_buffers_without_terminal_records(torch_cuda):
-    """The configuration bench.py times, at its real size: 2^20 boards, the STANDARD step kernel through g2048_rollout
-    over [K][B] uint8 action / float32 reward / uint8 terminated buffers, per-board terminal records OFF
-    (g2048_set_last_records(0)).  Every step's rewards and flags, the final boards and scores, the episode counters and
-    the exact return sum against the C oracle; the calls that need terminal records refuse; switching them on again
-    starts from "none yet" and from then on records exactly the episodes that end."""
+@pytest.mark.parametrize("chains", [1, 2])
+def test_bench_configuration_2p20_rollout_buffers_without_terminal_records(torch_cuda, monkeypatch, chains):
+    """The configuration bench.py times, at its real size and in BOTH launch forms it can take: 2^20 boards, the STANDARD
+    step kernel through g2048_rollout over [K][B] uint8 action / float32 reward / uint8 terminated buffers, per-board
+    terminal records OFF (g2048_set_last_records(0)); as one chain (one whole-batch launch per step: what the driver's
+    K = 20 line runs) and as TWO chains (two half-batch launches per step on two streams: bench.py's default from K = 200;
+    forced here for a 24-step rollout on a cold side chain by G2048_TWO_CHAIN_MIN_STEPS, which g2048_set_chains reads) --
+    `chains_used` says which form really ran.  Every step's rewards and flags, the final boards and scores, the episode
+    counters and the exact return sum against the C oracle; the calls that need terminal records refuse; switching them
+    on again starts from "none yet" and from then on records exactly the episodes that end."""
     torch = torch_cuda
     from gym2048_amd._lib import G2048Error
     from gym2048_amd.batched import Batched2048, parse_stats
     from oracle import OracleBatch
     n, seed, k = 1 << 20, 42, 24
-    eng, ora = Batched2048(n, seed=seed, last_records=False), OracleBatch(n, seed, threads=0)
-    assert not eng.last_records_enabled
+    if chains == 2:
+        monkeypatch.setenv("G2048_TWO_CHAIN_MIN_STEPS", "2")
+    eng, ora = Batched2048(n, seed=seed, last_records=False, chains=chains), OracleBatch(n, seed, threads=0)
+    assert not eng.last_records_enabled and eng.chains == chains
     eng.reset()
     ora.reset()
     acts = eng.random_actions(k)
     rew = torch.zeros((k, n), dtype=torch.float32, device=eng.device)
     term = torch.zeros((k, n), dtype=torch.uint8, device=eng.device)
     eng.prepare_rollout(acts, reward=rew, terminated=term).run()
+    assert eng.chains_used == chains, "the rollout did not run in the launch form this case is about"
     torch.cuda.synchronize()
     for j in range(k):
         ora.step(None)                                       # the synthetic policy = the generated actions
@@ -223,7 +230,7 @@ def test_two_rank_hip_shards_allgather(torch_cuda, tmp_path):
     ro = parse_stats(whole.episode_stats_device(returns_only=True))         # returns-only flavour: counts + exact return sum
     for key in ("episodes", "illegal_ends", "return_sum", "mean_episode_score"):
         assert ro[key] == st[key], key
-    assert ro["max_exp"] == 0 and not any(ro["highest_hist"]) and ro["last_count"] == ro["last_score_sum"] == 0
+    assert ro["max_exp"] == 0 and not any(ro["highest_hist"]) and ro["last_count"] is ro["last_score_sum"] is None
     assert int(got["return_sum"]) == st["return_sum"] > 0                   # the two shards' summaries add up to the whole
 
 
@@ -259,6 +266,10 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 20 and "forced_dist" in line["config"]
     assert line["value"] > 1e10 and line["episodes_finished"] > 0
+    # the line says what the process group really was, and runs in the same launch form as the N = 1 line at this K
+    cfg = line["config"]
+    assert cfg["backend"] == "nccl" and cfg["pg_world_size"] == 1 and cfg["gathered_rows"] == 1 and cfg["chains"] == 1
+    assert len(line["timing"]["k_region_repeats_us"]) == 5 and 0 < line["roofline"]["frac_wall"] <= line["roofline"]["frac"]
     t = line["timing"]
     assert t["launch_train_us"] > 0 and t["collective_us"] > 0
     print(f"forced-dist ({gather}): launch train {t['launch_train_us']:.1f} us, collective {t['collective_us']:.1f} us, "
@@ -297,6 +308,35 @@ def test_bench_gpus_2_launches_itself(torch_cuda, gather):
         g = line["global_returns"]                      # both ranks' summaries arrived: twice rank 0's shard, roughly
         assert 1.8 * line["episodes_finished"] < g["episodes"] < 2.2 * line["episodes_finished"]
     print(f"self-launched 2 ranks ({gather}): {line['value']:.3e} env-steps/s, timing {t}")
+
+
+def test_bench_gpus_8_rehearsal_on_one_device(torch_cuda):
+    """The driver's 8-GPU scaling command -- `python bench.py --gpus 8 --steps 20 --warmup 5` -- rehearsed end to end on
+    the one GPU there is: eight processes on cuda:0 (G2048_BENCH_SAME_DEVICE=1), gloo carrying the collectives (RCCL
+    refuses two ranks on one device), 2^17 boards per rank.  What this pins: the rendezvous of 8 ranks, the relay of rank
+    0's JSON as the LAST line, exit code 0, a wall time far inside the driver's 1 800 s -- and that the line describes
+    itself: backend, the process group's world size, 8 gathered rows, the launch form (one chain at K = 20, as at N = 1)."""
+    import json
+    import time
+    env = dict(os.environ, G2048_BENCH_BACKEND="gloo", G2048_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "G2048_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    t0 = time.time()
+    res = _run_bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--no-extras", "--boards", "131072",
+                      "--device-warmup", "0.05"], env)
+    took = time.time() - t0
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), lines[-3:]
+    line = json.loads(lines[-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert cfg["backend"] == "gloo" and cfg["pg_world_size"] == 8 and cfg["gathered_rows"] == 8
+    assert cfg["global_boards"] == 8 * cfg["boards_per_gpu"] == 8 * 131072 and cfg["chains"] == 1 and cfg["chains_requested"] == 1
+    g = line["global_returns"]
+    assert 6 * line["episodes_finished"] < g["episodes"] < 10 * line["episodes_finished"]      # eight shards' worth
+    assert line["value"] > 1e7 and len(line["timing"]["k_region_repeats_us"]) == 5
+    assert took < 600, f"the 8-rank rehearsal took {took:.0f} s"
+    print(f"8-rank rehearsal on one device: {took:.0f} s wall, value {line['value']:.3e}, timing {line['timing']}")
 
 
 def test_policy_loop_bench_small(torch_cuda):

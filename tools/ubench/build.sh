@@ -13,6 +13,11 @@ mkdir -p _r3
 for f in g2048_device.h g2048_kernels.h g2048_kernels.hip g2048_pcg64.h; do
     git show 1a3ea8e:gym-2048_amd/csrc/$f | sed 's/g2048/g2048r3/g; s/G2048/G2048R3/g' > _r3/$(echo $f | sed 's/g2048/g2048r3/')
 done
+# r5_probe compares against the round-4 kernels (commit 8baa390), every identifier renamed g2048 -> g2048r4
+mkdir -p _r4
+for f in g2048_device.h g2048_kernels.h g2048_kernels.hip g2048_pcg64.h; do
+    git show 8baa390:gym-2048_amd/csrc/$f | sed 's/g2048/g2048r4/g; s/G2048/G2048R4/g' > _r4/$(echo $f | sed 's/g2048/g2048r4/')
+done
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 for t in "$@"; do
     $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 -o $t $t.hip   # same flags as the product build
