@@ -440,6 +440,9 @@ def main():
         wp.run()
     elapsed, kernel_region_ms, collective_ms, gathered, sync_after_us = timed_region()   # THE timed region: `value`
     timed_chains = eng.chains_used
+    # sanity inside the bench: the rollout really happened (episodes finished, rewards written) -- the engine's books as
+    # they stand after THE timed region (what the gathered summaries describe)
+    stats = eng.episode_stats()
     # five further regions of the same K steps with the same brackets (not `value`: how much one 200 us sample moves)
     repeats = []
     for _ in range(5 if K <= 2000 else 0):
@@ -460,8 +463,6 @@ def main():
         assert gathered.numel() == (B * world if args.gather == "full" else stats_bytes * world)
         gathered_rows = int(gathered.shape[0]) if args.gather == "summary" else int(gathered.numel() // B)
 
-    # sanity inside the bench: the rollout really happened (episodes finished, rewards written)
-    stats = eng.episode_stats()
     total_steps = K * B * world
     value = total_steps / elapsed
     launch_us = kernel_region_ms * 1e3 / K

@@ -91,6 +91,7 @@ SIGNATURES = {
     "g2048_set_chains": (C.c_int, [_E, C.c_int]),
     "g2048_get_chains": (C.c_int, [_E]),
     "g2048_get_chains_used": (C.c_int, [_E]),
+    "g2048_get_graph_replays": (C.c_uint64, [_E]),
     "g2048_rollout_fused": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_random": (C.c_int, [_E, _u32, _S]),
     "g2048_move": (C.c_int, [_E, C.c_void_p, _i32, C.c_int, C.c_void_p, C.c_void_p, _S]),

@@ -170,6 +170,12 @@ class Batched2048:
         return int(self._lib.g2048_get_chains_used(self._h))
 
     @property
+    def graph_replays(self) -> int:
+        """Rollouts of this engine that were replayed from the cached hipGraph of their launch train (small batches,
+        standard outputs, the same buffers as the rollout before: ``g2048_get_graph_replays``)."""
+        return int(self._lib.g2048_get_graph_replays(self._h))
+
+    @property
     def last_records_enabled(self) -> bool:
         return bool(self._lib.g2048_get_last_records(self._h))
 

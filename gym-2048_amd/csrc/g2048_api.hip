@@ -111,6 +111,31 @@ struct g2048_engine {
     int poisoned = 0;
     char poison_msg[320] = "";
     int last_rollout_chains = 1; // what the most recent g2048_rollout did (g2048_get_chains_used)
+    // A rollout over the SAME buffers as the one before it is replayed from a cached hipGraph when the batch is small
+    // enough for the host's launch rate to be the limit (g2048_rollout; kGraphMaxBoards).  The key is everything the
+    // graph's frozen kernel arguments depend on; the clock comes through *graph_t_dev.
+    struct GraphKey {
+        uint32_t k_steps = 0;
+        uint64_t stride = 0, seed = 0, board_offset = 0;
+        const void *actions = nullptr;
+        float *reward = nullptr;
+        uint8_t *terminated = nullptr;
+        uint4 *last_record = nullptr;
+        int32_t action_dtype = 0;
+        int auto_reset = 0;
+        float illegal_reward = 0.0f;
+        bool operator==(const GraphKey &o) const
+        {
+            return k_steps == o.k_steps && stride == o.stride && seed == o.seed && board_offset == o.board_offset && actions == o.actions &&
+                   reward == o.reward && terminated == o.terminated && last_record == o.last_record && action_dtype == o.action_dtype &&
+                   auto_reset == o.auto_reset && std::memcmp(&illegal_reward, &o.illegal_reward, sizeof(float)) == 0;
+        }
+    };
+    GraphKey graph_key{}, graph_seen{}; // the cached graph's key / the key of the previous stream-launched candidate
+    g2048::RolloutGraph graph{};
+    unsigned long long *graph_t_dev = nullptr;
+    int graph_enabled = 1;              // G2048_ROLLOUT_GRAPH=0 (read by g2048_create) turns the form off; a failing graph call too
+    uint64_t graph_replays = 0;         // rollouts served from the cached graph (g2048_get_graph_replays)
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
@@ -265,6 +290,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     e->device = device;
     e->seed = seed;
     e->board_offset = board_offset;
+    if (const char *v = std::getenv("G2048_ROLLOUT_GRAPH"))
+        e->graph_enabled = std::atoi(v) != 0;
 
     const size_t n = n_boards;
     const size_t off_boards = 0;
@@ -335,6 +362,9 @@ int g2048_destroy(g2048_engine *e)
             (void)hipEventDestroy(e->fork_event);
         if (e->join_event)
             (void)hipEventDestroy(e->join_event);
+        g2048::destroy_rollout_graph(e->graph);
+        if (e->graph_t_dev)
+            (void)hipFree(e->graph_t_dev);
         if (e->chain_flags)
             (void)hipFree(e->chain_flags);
         if (e->chain_err_host)
@@ -510,6 +540,9 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
 // the side stream's first kernels start late.  Hence: warm, two chains from kTwoChainMinSteps; cold, only from
 // kTwoChainColdMinSteps, where 40 us are a few per cent.
 constexpr uint32_t kTwoChainMinSteps = 12, kTwoChainColdMinSteps = 64;
+// Cached-graph replay of a launch train (g2048_kernels.hip "a k-step launch train as a CACHED hipGraph"): up to 2^17 boards
+// -- where one host thread cannot issue launches as fast as the device retires them -- and from 8 steps.
+constexpr uint32_t kGraphMaxBoards = 1u << 17, kGraphMinSteps = 8;
 constexpr double kSideWarmWindowUs = 50000.0; // after the estimated end of the side chain's last work
 
 static int ensure_side_chain(g2048_engine *e)
@@ -613,6 +646,8 @@ int g2048_set_chains(g2048_engine *e, int chains)
     return G2048_OK;
 }
 
+uint64_t g2048_get_graph_replays(const g2048_engine *e) { return e ? e->graph_replays : 0; }
+
 int g2048_get_chains(const g2048_engine *e) { return e ? e->chains : 0; }
 int g2048_get_chains_used(const g2048_engine *e) { return e ? e->last_rollout_chains : 0; }
 
@@ -683,6 +718,54 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         a.t_hi = static_cast<uint32_t>(t >> 32);
         return a;
     };
+    if (!two && e->graph_enabled && n <= kGraphMaxBoards && k_steps >= kGraphMinSteps) {
+        // ---- small batch, same buffers as last time: replay the cached graph of this launch train
+        const g2048::StepArgs a0 = args_of(0);
+        if (g2048::rollout_graph_supported(a0)) {
+            g2048_engine::GraphKey key;
+            key.k_steps = k_steps; key.stride = stride; key.seed = e->seed; key.board_offset = e->board_offset;
+            key.actions = io->actions; key.reward = io->reward; key.terminated = io->terminated; key.last_record = a0.st.last_record;
+            key.action_dtype = io->action_dtype; key.auto_reset = auto_reset ? 1 : 0; key.illegal_reward = e->illegal_reward;
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+            if (capturing)
+                (void)hipGetLastError();
+            bool have = !capturing && e->graph.exec && key == e->graph_key;
+            if (!capturing && !have && key == e->graph_seen) {
+                // the second rollout over these buffers in a row: worth a graph (building one costs about half a train)
+                g2048::destroy_rollout_graph(e->graph);
+                hipError_t err = hipSuccess;
+                if (!e->graph_t_dev) {
+                    err = hipMalloc(reinterpret_cast<void **>(&e->graph_t_dev), 256);
+                    if (err == hipSuccess)
+                        err = hipMemset(e->graph_t_dev, 0, 256);
+                    if (err == hipSuccess)
+                        err = hipStreamSynchronize(nullptr); // (hipMemset only enqueues the fill)
+                }
+                if (err == hipSuccess)
+                    err = g2048::build_rollout_graph(a0, io->action_dtype, k_steps, stride, e->graph_t_dev, &e->graph);
+                if (err == hipSuccess) {
+                    e->graph_key = key;
+                    have = true;
+                } else {
+                    (void)hipGetLastError(); // not fatal: this engine keeps launching by stream
+                    e->graph_enabled = 0;
+                }
+            }
+            e->graph_seen = key;
+            if (have) {
+                const hipError_t err = g2048::launch_rollout_graph(e->graph, t0 + 1u, s);
+                if (err == hipSuccess) {
+                    ++e->graph_replays;
+                    return G2048_OK;
+                }
+                // nothing was enqueued (the launch of a graph is all or nothing): fall through to stream launches
+                (void)hipGetLastError();
+                g2048::destroy_rollout_graph(e->graph);
+                e->graph_enabled = 0;
+            }
+        }
+    }
     if (!two) {
         for (uint32_t j = 0; j < k_steps; ++j) {
             const g2048::StepArgs a = args_of(j);

@@ -72,6 +72,18 @@ struct StatsOut {
 hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s);
 hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s);
 hipError_t launch_rollout_random(const StepArgs &a, hipStream_t s);
+// a k-step launch train as a cached hipGraph: [set clock] -> k x step (t read from *t_dev); see g2048_kernels.hip
+struct RolloutGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t set_node = nullptr;
+    unsigned long long *t_dev = nullptr;
+};
+bool rollout_graph_supported(const StepArgs &a); // the standard configuration: reward + terminated, nothing optional, spawn stream
+hipError_t build_rollout_graph(const StepArgs &first, int action_dtype, uint32_t k_steps, uint64_t stride, unsigned long long *t_dev,
+                               RolloutGraph *out);
+hipError_t launch_rollout_graph(RolloutGraph &g, unsigned long long t_first, hipStream_t s);
+void destroy_rollout_graph(RolloutGraph &g);
 hipError_t launch_rollout_fused(const StepArgs &a, int action_dtype, uint64_t stride, hipStream_t s);
 hipError_t launch_move(uint4 *boards, uint32_t n, const void *actions, int action_dtype, bool trial,
                        int32_t *score_out, uint8_t *legal_out, hipStream_t s);

@@ -469,12 +469,10 @@ struct StepTail {
 // one-hot of the record it leaves behind is written by emit_onehot (+256 / 512 / 1 024 B per board; the dtype is a
 // wave-uniform switch, one taken branch against hundreds of store-bound instructions).
 template <int ACT, bool FULL, bool STD, bool HAS_OBS>
-__global__ void __launch_bounds__(kBlock)
-step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
-            uint32_t seed_hi, uint32_t t_lo, uint32_t t_hi, uint32_t n, float *reward, const StepTail tail)
+__device__ __forceinline__ void step_body(WaveTables *s_tables, uint4 *s_recs, uint4 *boards, const void *actions,
+                                          unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo, uint32_t seed_hi,
+                                          uint32_t t_lo, uint32_t t_hi, uint32_t n, float *reward, const StepTail &tail)
 {
-    __shared__ WaveTables s_tables[kBlock / 64];
-    __shared__ uint4 s_recs[HAS_OBS ? kBlock : 1];
     StepArgs p{};
     p.st.boards = boards;
     p.st.last_record = tail.last_record;
@@ -539,6 +537,39 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
         emit_onehot<FULL>(s_recs + (threadIdx.x & ~63u), rec, tail.obs, tail.obs_dtype, i_raw & ~63u, n);
     if (!STD && tail.done_seq)
         signal_done(tail.done_seq, tail.done_value);
+}
+
+template <int ACT, bool FULL, bool STD, bool HAS_OBS>
+__global__ void __launch_bounds__(kBlock)
+step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
+            uint32_t seed_hi, uint32_t t_lo, uint32_t t_hi, uint32_t n, float *reward, const StepTail tail)
+{
+    __shared__ WaveTables s_tables[kBlock / 64];
+    __shared__ uint4 s_recs[HAS_OBS ? kBlock : 1];
+    step_body<ACT, FULL, STD, HAS_OBS>(s_tables, s_recs, boards, actions, ep_counters, board_offset, seed_lo, seed_hi, t_lo, t_hi, n,
+                                       reward, tail);
+}
+
+// The same step with the transaction counter read from DEVICE MEMORY: t = *t_ptr + j.  This is the node of a CACHED
+// hipGraph of a k-step launch train (launch_rollout_graph below): the graph's kernel arguments are frozen when it is
+// built, so everything that differs between two rollouts over the same buffers -- only t -- comes through memory, written
+// by the one-lane set_clock_kernel node in front of the train.  Standard configuration only (reward + terminated, no
+// optional output).  The s_load of t (uniform address, scalar cache) is in flight together with the board load.
+__global__ void __launch_bounds__(64) set_clock_kernel(unsigned long long *t_ptr, unsigned long long value)
+{
+    if (threadIdx.x == 0)
+        *t_ptr = value;
+}
+
+template <int ACT, bool FULL>
+__global__ void __launch_bounds__(kBlock)
+step_graph_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters, uint32_t board_offset, uint32_t seed_lo,
+                  uint32_t seed_hi, const unsigned long long *t_ptr, uint32_t n, uint32_t j, float *reward, const StepTail tail)
+{
+    __shared__ WaveTables s_tables[kBlock / 64];
+    const unsigned long long t = *t_ptr + j;
+    step_body<ACT, FULL, true, false>(s_tables, nullptr, boards, actions, ep_counters, board_offset, seed_lo, seed_hi,
+                                      static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), n, reward, tail);
 }
 
 // ------------------------------------------------------------------------- fused rollout
@@ -1461,6 +1492,112 @@ hipError_t launch_reset_numpy(const StepArgs &a, const uint8_t *mask, hipStream_
         return hipSuccess;
     hipLaunchKernelGGL(reset_numpy_kernel, grid_for(a.n), dim3(kBlock), 0, s, a, mask);
     return hipGetLastError();
+}
+
+// ---- a k-step launch train as a CACHED hipGraph (small batches)
+// At 65 536 boards a step kernel takes ~2.4 us on the device and one host thread issues a launch every 3.0-4.6 us: the
+// per-step path is host-issue-bound (tools/ubench/r5_probe.hip: 3.0-4.6 us per step by stream launches, 2.43-2.45 us as a
+// graph replay; 2^17 boards 2.9-3.6 vs 2.95-2.99; from 2^18 boards on the kernel is the longer of the two and the forms tie).
+// The graph is [set_clock_kernel] -> k x step_graph_kernel, explicit nodes in a chain; building and instantiating it costs
+// ~1.8 us per node (less than launching the same train once), replaying it one hipGraphExecKernelNodeSetParams (the new
+// clock value, 2.5 us) + one hipGraphLaunch.
+bool rollout_graph_supported(const StepArgs &a)
+{
+    return a.n != 0 && a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0 && !a.boards_out &&
+           !a.done_seq && !a.obs && !a.st.rng;
+}
+
+static void *step_graph_function(int action_dtype, bool full)
+{
+    switch (action_dtype * 2 + (full ? 1 : 0)) {
+    case 0: return reinterpret_cast<void *>(step_graph_kernel<0, false>);
+    case 1: return reinterpret_cast<void *>(step_graph_kernel<0, true>);
+    case 2: return reinterpret_cast<void *>(step_graph_kernel<1, false>);
+    case 3: return reinterpret_cast<void *>(step_graph_kernel<1, true>);
+    case 4: return reinterpret_cast<void *>(step_graph_kernel<2, false>);
+    case 5: return reinterpret_cast<void *>(step_graph_kernel<2, true>);
+    case 6: return reinterpret_cast<void *>(step_graph_kernel<3, false>);
+    case 7: return reinterpret_cast<void *>(step_graph_kernel<3, true>);
+    default: return nullptr;
+    }
+}
+
+void destroy_rollout_graph(RolloutGraph &g)
+{
+    if (g.exec)
+        (void)hipGraphExecDestroy(g.exec);
+    if (g.graph)
+        (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr;
+    g.graph = nullptr;
+    g.set_node = nullptr;
+}
+
+// `first`: the arguments of step 0 (its t is ignored); step j reads / writes its I/O j * stride elements further on.
+hipError_t build_rollout_graph(const StepArgs &first, int action_dtype, uint32_t k_steps, uint64_t stride, unsigned long long *t_dev,
+                               RolloutGraph *out)
+{
+    static const size_t act_bytes[4] = {0, 1, 4, 8};
+    void *fn = step_graph_function(action_dtype, first.n % kBlock == 0);
+    if (!fn || !rollout_graph_supported(first) || !t_dev || !out)
+        return hipErrorInvalidValue;
+    RolloutGraph g{};
+    g.t_dev = t_dev;
+    hipError_t err = hipGraphCreate(&g.graph, 0);
+    if (err != hipSuccess)
+        return err;
+    unsigned long long value = 0;
+    void *set_args[2] = {&g.t_dev, &value};
+    hipKernelNodeParams sp{};
+    sp.func = reinterpret_cast<void *>(set_clock_kernel);
+    sp.gridDim = dim3(1);
+    sp.blockDim = dim3(64);
+    sp.kernelParams = set_args;
+    err = hipGraphAddKernelNode(&g.set_node, g.graph, nullptr, 0, &sp);
+    hipGraphNode_t prev = g.set_node;
+    for (uint32_t j = 0; j < k_steps && err == hipSuccess; ++j) {
+        const size_t off = static_cast<size_t>(j) * stride;
+        uint4 *boards = first.st.boards;
+        const void *actions = first.actions ? static_cast<const char *>(first.actions) + off * act_bytes[action_dtype] : nullptr;
+        unsigned long long *ep = first.st.ep_counters;
+        uint32_t board_offset = first.board_offset, seed_lo = first.seed_lo, seed_hi = first.seed_hi, n = first.n, jj = j;
+        const unsigned long long *t_ptr = t_dev;
+        float *reward = first.reward + off;
+        StepTail tail{first.terminated + off, first.st.last_record, nullptr, nullptr, nullptr, first.illegal_reward, 0u, first.auto_reset,
+                      nullptr, 0u, nullptr, nullptr, 0ull};
+        void *args[11] = {&boards, &actions, &ep, &board_offset, &seed_lo, &seed_hi, &t_ptr, &n, &jj, &reward, &tail};
+        hipKernelNodeParams kp{};
+        kp.func = fn;
+        kp.gridDim = grid_for(first.n);
+        kp.blockDim = dim3(kBlock);
+        kp.kernelParams = args;
+        hipGraphNode_t node = nullptr;
+        err = hipGraphAddKernelNode(&node, g.graph, &prev, 1, &kp);
+        prev = node;
+    }
+    if (err == hipSuccess)
+        err = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+    if (err != hipSuccess) {
+        destroy_rollout_graph(g);
+        return err;
+    }
+    *out = g;
+    return hipSuccess;
+}
+
+// Replay: step j of the train plays transaction t_first + j.
+hipError_t launch_rollout_graph(RolloutGraph &g, unsigned long long t_first, hipStream_t s)
+{
+    void *set_args[2] = {&g.t_dev, &t_first};
+    hipKernelNodeParams sp{};
+    sp.func = reinterpret_cast<void *>(set_clock_kernel);
+    sp.gridDim = dim3(1);
+    sp.blockDim = dim3(64);
+    sp.kernelParams = set_args;
+    hipError_t err = hipGraphExecKernelNodeSetParams(g.exec, g.set_node, &sp);
+    if (err != hipSuccess)
+        return err;
+    return hipGraphLaunch(g.exec, s);
 }
 
 hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s)

@@ -430,6 +430,78 @@ def test_two_chain_ticket_that_does_not_arrive_in_time_is_loud(torch_cuda, monke
     eng.close()                                                  # destroying it is what is left to do, and works
 
 
+@pytest.mark.parametrize("n,adt", [(65536, "uint8"), (5000, "int64"), (1 << 17, "int32")])
+def test_small_batch_rollouts_are_replayed_from_a_cached_graph(torch_cuda, monkeypatch, n, adt):
+    """BASELINE configs[1] territory (<= 2^17 boards): the second and every further g2048_rollout in a row over the same
+    buffers is a hipGraph replay of its launch train (step_graph_kernel reads the clock from device memory).  Same games:
+    every replay's rewards and flags, the boards, scores and the return accounting against the oracle; whole-block and
+    ragged batches, every action dtype, a non-default stream; a single step between two replays (the clock moves on); a
+    change of what the graph froze (terminal records on) falls back to stream launches once and rebuilds; the knob."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    seed, k = 9, 24
+    eng, ora = Batched2048(n, seed=seed, last_records=False), OracleBatch(n, seed, threads=0)
+    eng.reset()
+    ora.reset()
+    dev = eng.device
+    acts8 = torch.zeros((k, n), dtype=torch.uint8, device=dev)
+    acts = torch.zeros((k, n), dtype=getattr(torch, adt), device=dev)
+    rew = torch.zeros((k, n), dtype=torch.float32, device=dev)
+    term = torch.zeros((k, n), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+
+    def one_rollout(expect_replays):
+        with torch.cuda.stream(stream):
+            eng.random_actions(k, out=acts8)
+            acts.copy_(acts8)                               # same buffer every time: that is what makes the train replayable
+            rew.zero_()
+            term.zero_()
+            plan.run()
+        stream.synchronize()
+        for j in range(k):
+            ora.step(None)
+            assert np.array_equal(rew[j].cpu().numpy(), ora.reward), (j, expect_replays)
+            assert np.array_equal(term[j].cpu().numpy(), ora.terminated), (j, expect_replays)
+        assert eng.graph_replays == expect_replays
+
+    with torch.cuda.stream(stream):
+        plan = eng.prepare_rollout(acts, reward=rew, terminated=term)
+    one_rollout(0)                                          # first sight of these buffers: launched kernel by kernel
+    one_rollout(1)                                          # second in a row: graph built, replayed
+    one_rollout(2)
+    eng.step(None)                                          # something else in between: the clock the next replay gets has moved
+    ora.step(None)
+    one_rollout(3)
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards) and np.array_equal(eng.get_scores(), ora.score)
+    eng.set_last_records(True)                              # the graph froze "no terminal records": not this rollout's train any more
+    one_rollout(3)
+    one_rollout(4)                                          # rebuilt
+    st = eng.episode_stats()
+    assert st["episodes"] == int(ora.ep_count.sum()) and st["return_sum"] == ora.return_sum == ora.finished_return_sum
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards) and np.array_equal(eng.get_scores(), ora.score)
+    eng.close()
+    # the knob: read by g2048_create
+    monkeypatch.setenv("G2048_ROLLOUT_GRAPH", "0")
+    off = Batched2048(n, seed=seed)
+    off.reset()
+    for _ in range(3):
+        off.rollout(acts8, reward=rew, terminated=term)
+    torch.cuda.synchronize()
+    assert off.graph_replays == 0
+    off.close()
+    monkeypatch.delenv("G2048_ROLLOUT_GRAPH")
+    # optional outputs are not the standard train: never replayed
+    opt = Batched2048(n, seed=seed)
+    opt.reset()
+    ill = torch.zeros((k, n), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        opt.rollout(acts8, reward=rew, terminated=term, illegal=ill)
+    torch.cuda.synchronize()
+    assert opt.graph_replays == 0
+    opt.close()
+
+
 def test_rollout_writes_terminal_boards(torch_cuda):
     """terminal_boards through g2048_rollout: row [j, i] is written exactly where step j ended board i's
     episode and holds the board the episode ended on."""
