@@ -88,6 +88,7 @@ SIGNATURES = {
     "g2048_stream_signal": (C.c_int, [_E, _S, C.POINTER(_u64)]),
     "g2048_stream_wait": (C.c_int, [_E, _u64, _S]),
     "g2048_rollout": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
+    "g2048_rollout_prepare": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int]),
     "g2048_set_chains": (C.c_int, [_E, C.c_int]),
     "g2048_get_chains": (C.c_int, [_E]),
     "g2048_get_chains_used": (C.c_int, [_E]),

@@ -55,6 +55,15 @@ class _RolloutPlan:
         check(self._fn(e._h, self._k, self._io_ref, e.n_envs, self._auto_reset, e._stream()))
         e._fresh = False
 
+    def prepare_graph(self):
+        """Build the cached hipGraph of this plan's launch train now (``g2048_rollout_prepare``: no step is executed), so
+        that the first ``run()`` already is a replay.  A no-op where the form does not apply (large batches, optional
+        outputs, numpy-RNG mode, fused plans).  The engine keeps the graphs of its four most recently built plans."""
+        e = self._engine
+        if self._fn is e._lib.g2048_rollout:
+            check(e._lib.g2048_rollout_prepare(e._h, self._k, self._io_ref, e.n_envs, self._auto_reset))
+        return self
+
 
 class Batched2048:
     """``n_envs`` boards resident on ``cuda:device``; the batched counterpart of ``Game2048Env``.

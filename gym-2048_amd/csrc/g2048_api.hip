@@ -131,9 +131,16 @@ struct g2048_engine {
                    auto_reset == o.auto_reset && std::memcmp(&illegal_reward, &o.illegal_reward, sizeof(float)) == 0;
         }
     };
-    GraphKey graph_key{}, graph_seen{}; // the cached graph's key / the key of the previous stream-launched candidate
-    g2048::RolloutGraph graph{};
+    struct GraphEntry {
+        GraphKey key{};
+        g2048::RolloutGraph g{};
+    };
+    static constexpr int kGraphSlots = 4;  // a trainer alternates between a few sets of rollout buffers at most
+    GraphEntry graphs[kGraphSlots];        // the cached graphs, replaced round robin
+    int graph_next = 0;
+    GraphKey graph_seen{};                 // the key of the previous rollout that was eligible (cached or not)
     unsigned long long *graph_t_dev = nullptr;
+    uint32_t graph_max_boards = 1u << 17; // batches up to this size use the form (G2048_GRAPH_MAX_BOARDS, read by g2048_create)
     int graph_enabled = 1;              // G2048_ROLLOUT_GRAPH=0 (read by g2048_create) turns the form off; a failing graph call too
     uint64_t graph_replays = 0;         // rollouts served from the cached graph (g2048_get_graph_replays)
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
@@ -292,6 +299,11 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     e->board_offset = board_offset;
     if (const char *v = std::getenv("G2048_ROLLOUT_GRAPH"))
         e->graph_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("G2048_GRAPH_MAX_BOARDS")) { // measurement knob
+        const long long m = std::atoll(v);
+        if (m >= 0 && m <= 0xffffffffll)
+            e->graph_max_boards = static_cast<uint32_t>(m);
+    }
 
     const size_t n = n_boards;
     const size_t off_boards = 0;
@@ -362,7 +374,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipEventDestroy(e->fork_event);
         if (e->join_event)
             (void)hipEventDestroy(e->join_event);
-        g2048::destroy_rollout_graph(e->graph);
+        for (auto &entry : e->graphs)
+            g2048::destroy_rollout_graph(entry.g);
         if (e->graph_t_dev)
             (void)hipFree(e->graph_t_dev);
         if (e->chain_flags)
@@ -542,7 +555,7 @@ static g2048::StepArgs part_of(g2048::StepArgs a, int action_dtype, uint32_t fir
 constexpr uint32_t kTwoChainMinSteps = 12, kTwoChainColdMinSteps = 64;
 // Cached-graph replay of a launch train (g2048_kernels.hip "a k-step launch train as a CACHED hipGraph"): up to 2^17 boards
 // -- where one host thread cannot issue launches as fast as the device retires them -- and from 8 steps.
-constexpr uint32_t kGraphMaxBoards = 1u << 17, kGraphMinSteps = 8;
+constexpr uint32_t kGraphMinSteps = 8; // (the size limit is g2048_engine::graph_max_boards)
 constexpr double kSideWarmWindowUs = 50000.0; // after the estimated end of the side chain's last work
 
 static int ensure_side_chain(g2048_engine *e)
@@ -651,6 +664,70 @@ uint64_t g2048_get_graph_replays(const g2048_engine *e) { return e ? e->graph_re
 int g2048_get_chains(const g2048_engine *e) { return e ? e->chains : 0; }
 int g2048_get_chains_used(const g2048_engine *e) { return e ? e->last_rollout_chains : 0; }
 
+static g2048_engine::GraphKey graph_key_of(const g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride,
+                                           int auto_reset, const g2048::StepArgs &a0)
+{
+    g2048_engine::GraphKey key;
+    key.k_steps = k_steps; key.stride = stride; key.seed = e->seed; key.board_offset = e->board_offset;
+    key.actions = io->actions; key.reward = io->reward; key.terminated = io->terminated; key.last_record = a0.st.last_record;
+    key.action_dtype = io->action_dtype; key.auto_reset = auto_reset ? 1 : 0; key.illegal_reward = e->illegal_reward;
+    return key;
+}
+
+static g2048_engine::GraphEntry *find_graph(g2048_engine *e, const g2048_engine::GraphKey &key)
+{
+    for (auto &entry : e->graphs)
+        if (entry.g.exec && entry.key == key)
+            return &entry;
+    return nullptr;
+}
+
+// Build the cached graph for `key` in the next slot (round robin).  A failure is not fatal: the engine keeps launching by
+// stream, and stops trying.
+static g2048_engine::GraphEntry *build_graph(g2048_engine *e, const g2048_engine::GraphKey &key, const g2048::StepArgs &a0,
+                                             int action_dtype, uint32_t k_steps, uint64_t stride)
+{
+    g2048_engine::GraphEntry *slot = &e->graphs[e->graph_next];
+    e->graph_next = (e->graph_next + 1) % g2048_engine::kGraphSlots;
+    g2048::destroy_rollout_graph(slot->g);
+    hipError_t err = hipSuccess;
+    if (!e->graph_t_dev) {
+        err = hipMalloc(reinterpret_cast<void **>(&e->graph_t_dev), 256);
+        if (err == hipSuccess)
+            err = hipMemset(e->graph_t_dev, 0, 256);
+        if (err == hipSuccess)
+            err = hipStreamSynchronize(nullptr); // (hipMemset only enqueues the fill)
+    }
+    if (err == hipSuccess)
+        err = g2048::build_rollout_graph(a0, action_dtype, k_steps, stride, e->graph_t_dev, &slot->g);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        e->graph_enabled = 0;
+        return nullptr;
+    }
+    slot->key = key;
+    return slot;
+}
+
+int g2048_rollout_prepare(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset)
+{
+    if (int rc = usable(e))
+        return rc;
+    if (int rc = check_io(io))
+        return rc;
+    G2048_HIP(hipSetDevice(e->device));
+    if (!e->graph_enabled || e->n > e->graph_max_boards || k_steps < kGraphMinSteps)
+        return G2048_OK; // this rollout is launched kernel by kernel whatever happens: nothing to prepare
+    g2048_step_io s0 = *io;
+    const g2048::StepArgs a0 = make_args(e, &s0, auto_reset);
+    if (!g2048::rollout_graph_supported(a0))
+        return G2048_OK;
+    const g2048_engine::GraphKey key = graph_key_of(e, k_steps, io, stride, auto_reset, a0);
+    if (!find_graph(e, key))
+        (void)build_graph(e, key, a0, io->action_dtype, k_steps, stride);
+    return G2048_OK;
+}
+
 int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                   void *stream)
 {
@@ -718,50 +795,28 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
         a.t_hi = static_cast<uint32_t>(t >> 32);
         return a;
     };
-    if (!two && e->graph_enabled && n <= kGraphMaxBoards && k_steps >= kGraphMinSteps) {
-        // ---- small batch, same buffers as last time: replay the cached graph of this launch train
+    if (!two && e->graph_enabled && n <= e->graph_max_boards && k_steps >= kGraphMinSteps) {
+        // ---- same buffers as last time (or a prepared plan): replay the cached graph of this launch train
         const g2048::StepArgs a0 = args_of(0);
         if (g2048::rollout_graph_supported(a0)) {
-            g2048_engine::GraphKey key;
-            key.k_steps = k_steps; key.stride = stride; key.seed = e->seed; key.board_offset = e->board_offset;
-            key.actions = io->actions; key.reward = io->reward; key.terminated = io->terminated; key.last_record = a0.st.last_record;
-            key.action_dtype = io->action_dtype; key.auto_reset = auto_reset ? 1 : 0; key.illegal_reward = e->illegal_reward;
+            const g2048_engine::GraphKey key = graph_key_of(e, k_steps, io, stride, auto_reset, a0);
             hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
             if (capturing)
                 (void)hipGetLastError();
-            bool have = !capturing && e->graph.exec && key == e->graph_key;
-            if (!capturing && !have && key == e->graph_seen) {
-                // the second rollout over these buffers in a row: worth a graph (building one costs about half a train)
-                g2048::destroy_rollout_graph(e->graph);
-                hipError_t err = hipSuccess;
-                if (!e->graph_t_dev) {
-                    err = hipMalloc(reinterpret_cast<void **>(&e->graph_t_dev), 256);
-                    if (err == hipSuccess)
-                        err = hipMemset(e->graph_t_dev, 0, 256);
-                    if (err == hipSuccess)
-                        err = hipStreamSynchronize(nullptr); // (hipMemset only enqueues the fill)
-                }
-                if (err == hipSuccess)
-                    err = g2048::build_rollout_graph(a0, io->action_dtype, k_steps, stride, e->graph_t_dev, &e->graph);
-                if (err == hipSuccess) {
-                    e->graph_key = key;
-                    have = true;
-                } else {
-                    (void)hipGetLastError(); // not fatal: this engine keeps launching by stream
-                    e->graph_enabled = 0;
-                }
-            }
+            g2048_engine::GraphEntry *have = capturing ? nullptr : find_graph(e, key);
+            if (!capturing && !have && key == e->graph_seen) // the second rollout over these buffers in a row: worth a graph
+                have = build_graph(e, key, a0, io->action_dtype, k_steps, stride);
             e->graph_seen = key;
             if (have) {
-                const hipError_t err = g2048::launch_rollout_graph(e->graph, t0 + 1u, s);
+                const hipError_t err = g2048::launch_rollout_graph(have->g, t0 + 1u, s);
                 if (err == hipSuccess) {
                     ++e->graph_replays;
                     return G2048_OK;
                 }
                 // nothing was enqueued (the launch of a graph is all or nothing): fall through to stream launches
                 (void)hipGetLastError();
-                g2048::destroy_rollout_graph(e->graph);
+                g2048::destroy_rollout_graph(have->g);
                 e->graph_enabled = 0;
             }
         }

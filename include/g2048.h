@@ -230,6 +230,9 @@ int g2048_get_chains_used(const g2048_engine *e);
  * kernels, bit-identical results; nothing to configure (G2048_ROLLOUT_GRAPH=0 in the environment of g2048_create turns
  * it off).  Returns how many rollouts of this engine were served that way. */
 uint64_t g2048_get_graph_replays(const g2048_engine *e);
+/* Plan preparation: build the cached graph for exactly this rollout NOW (no step is executed, nothing is enqueued), so that
+ * already the first g2048_rollout with these arguments is a replay.  A no-op where the form does not apply. */
+int g2048_rollout_prepare(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset);
 
 /* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /
  * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead

@@ -500,6 +500,23 @@ def test_small_batch_rollouts_are_replayed_from_a_cached_graph(torch_cuda, monke
     torch.cuda.synchronize()
     assert opt.graph_replays == 0
     opt.close()
+    # a PREPARED plan is a replay from its first run on (g2048_rollout_prepare executes nothing), four plans are kept
+    pre, twin = Batched2048(n, seed=seed), OracleBatch(n, seed, threads=0)
+    pre.reset()
+    twin.reset()
+    bufs = [(torch.zeros((k, n), dtype=torch.float32, device=dev), torch.zeros((k, n), dtype=torch.uint8, device=dev)) for _ in range(4)]
+    plans = [pre.prepare_rollout(k, reward=r, terminated=t).prepare_graph() for r, t in bufs]     # the synthetic policy (ACT 0)
+    assert pre.clock == 0 and pre.graph_replays == 0
+    for rep in range(2):
+        for q, (r, t) in enumerate(bufs):
+            plans[q].run()
+            torch.cuda.synchronize()
+            for j in range(k):
+                twin.step(None)
+                assert np.array_equal(r[j].cpu().numpy(), twin.reward) and np.array_equal(t[j].cpu().numpy(), twin.terminated), (rep, q, j)
+    assert pre.graph_replays == 8
+    assert np.array_equal(pre.get_boards().reshape(n, 16), twin.boards) and np.array_equal(pre.get_scores(), twin.score)
+    pre.close()
 
 
 def test_rollout_writes_terminal_boards(torch_cuda):
