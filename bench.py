@@ -139,6 +139,7 @@ def python_port_rate() -> float:
 
 CSRC_FILES = ("gym-2048_amd/csrc/g2048_device.h", "gym-2048_amd/csrc/g2048_kernels.hip",
               "gym-2048_amd/csrc/g2048_kernels.h", "gym-2048_amd/csrc/g2048_api.hip", "gym-2048_amd/csrc/g2048_pcg64.h",
+              "gym-2048_amd/csrc/g2048_side_launcher.h",
               "include/g2048.h")
 
 
@@ -671,9 +672,10 @@ def main():
             del obs, oplan
         except Exception as exc:  # pragma: no cover
             extras["step_with_obs_u8"] = {"error": str(exc)}
-        # (a4) BASELINE configs[1]: 65 536 boards on one GPU, the same kernel, one chain; 200-launch trains over [200][65536]
+        # (a4) BASELINE configs[1]: 65 536 boards on one GPU, the same kernel, one chain; 200-step rollouts over [200][65536]
         #      buffers, best of 3 (SURVEY 8d "Config 2").  256 workgroups = one per CU: the launch is one latency chain, and
-        #      one host thread issues a launch every ~3 us -- this size is launch-bound, not HBM-bound
+        #      one host thread issues a launch every 3-4.6 us -- this size is launch-bound, not HBM-bound -- so the rollout is
+        #      replayed from a cached hipGraph of its launch train
         try:
             ns, ks = 1 << 16, 200
             small = Batched2048(ns, device=local_rank, seed=SEED, last_records=keep_last, chains=1)
@@ -682,7 +684,7 @@ def main():
             sa_ = small.random_actions(ks)
             sr_ = torch.zeros((ks, ns), dtype=torch.float32, device=dev)
             st2 = torch.zeros((ks, ns), dtype=torch.uint8, device=dev)
-            splan = small.prepare_rollout(sa_, reward=sr_, terminated=st2)
+            splan = small.prepare_rollout(sa_, reward=sr_, terminated=st2).prepare_graph()   # <= 2^17 boards: a cached hipGraph
             splan.run()
             runs = []
             for _ in range(3):
@@ -703,6 +705,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             extras["batch_65536"] = {"boards": ns, "launches": ks, "launch_us": us, "launch_us_runs": runs, "steps_per_s": ns / (us * 1e-6),
+                                     "form": ("the launch train replayed from the engine's cached hipGraph (g2048_rollout_prepare)"
+                                              if small.graph_replays else "stream launches"), "graph_replays": small.graph_replays,
                                      "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * ns / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                      "fused_rollout_with_io_steps_per_s": ks * ns / (e0.elapsed_time(e1) * 1e-3)}
             small.close()
