@@ -32,7 +32,9 @@ python tools/rocpd_summary.py --concurrency $O/stats2/r_results.db > $O/summary_
 grep -h '"metric"' $O/stats2.log > $O/bench_two_chains_under_rocprof.json
 # the same with the extras (the observation-writing step kernel, fused rollouts, the 2^24 streaming run, ...):
 # kernel-trace statistics of every kernel, and the HBM traffic counters of the step kernel that writes observations
-BENCHX="python bench.py --steps 200 --warmup 20 --cpu-seconds 1 $*"
+# (one chain: counter collection serialises kernels ACROSS queues, so the ticket kernels of a two-chain rollout would wait
+#  for each other until their bound runs out -- loudly, since round 5)
+BENCHX="python bench.py --chains 1 --steps 200 --warmup 20 --cpu-seconds 1 $*"
 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/statsx -o r -- $BENCHX > $O/statsx.log 2>&1
 cp $O/statsx/r_kernel_stats.csv $O/kernel_stats_extras.csv 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcx_fetch -o r -- $BENCHX > $O/pmcx_fetch.log 2>&1
