@@ -36,8 +36,8 @@ ADT = [torch.uint8, torch.int32, torch.int64]
 counts = {}
 
 
-def bump(name):
-    counts[name] = counts.get(name, 0) + 1
+def bump(name, by=1):
+    counts[name] = counts.get(name, 0) + by
 
 
 def check_state(eng, ora, where, always_auto_reset=False):
@@ -81,10 +81,11 @@ def one_case(case):
     dev = eng.device
     bump("numpy_mode_cases" if numpy_mode else "philox_cases")
     tag = f"case {case}: n={n} seed={seed} offset={offset} irw={irw} max_tile={max_tile} auto_reset={auto_reset} numpy={numpy_mode} chains={chains}"
+    replay_bufs = replay_plan = None
     for call in range(int(rs.integers(12, 40))):
-        kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state", "set_scores"],
-                             p=[0.3, 0.18, 0.15, 0.08, 0.1, 0.06, 0.04, 0.06, 0.03]))
-        if numpy_mode and kind in ("fused", "random", "mask_reset"):   # spawn-stream-only calls / unmaskable oracle reset
+        kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state", "set_scores", "replay"],
+                             p=[0.26, 0.16, 0.13, 0.08, 0.1, 0.06, 0.04, 0.06, 0.03, 0.08]))
+        if numpy_mode and kind in ("fused", "random", "mask_reset", "replay"):   # spawn-stream-only calls / unmaskable oracle reset
             kind = "step"
         where = f"{tag} call {call} {kind}"
         bump(kind)
@@ -134,6 +135,27 @@ def one_case(case):
                     assert np.array_equal(got, ora.onehot().astype(got.dtype)), (where, j)
                 if bout is not None:
                     assert np.array_equal(bout[j].cpu().numpy(), ora.boards), (where, j)
+        elif kind == "replay":
+            # the SAME [k, n] buffers rollout after rollout (what a trainer with fixed rollout buffers does): from the second
+            # one in a row -- or the first, when the plan was prepared -- g2048_rollout replays its cached hipGraph
+            if replay_bufs is None:
+                kg = int(rs.integers(8, 20))
+                replay_bufs = (torch.zeros((kg, n), dtype=ADT[int(rs.integers(0, 3))], device=dev),
+                               torch.zeros((kg, n), dtype=torch.float32, device=dev), torch.zeros((kg, n), dtype=torch.uint8, device=dev))
+                replay_plan = eng.prepare_rollout(replay_bufs[0], reward=replay_bufs[1], terminated=replay_bufs[2], auto_reset=auto_reset)
+                if rs.random() < 0.5:
+                    replay_plan.prepare_graph()
+            acts, rew, term = replay_bufs
+            for _ in range(int(rs.integers(1, 4))):
+                a = rs.integers(0, 4, acts.shape).astype(np.uint8)
+                acts.copy_(torch.as_tensor(a).to(dev))
+                before = eng.graph_replays
+                replay_plan.run()
+                bump("graph_replays", eng.graph_replays - before)
+                for j in range(acts.shape[0]):
+                    ora.step(a[j], auto_reset=auto_reset)
+                    assert np.array_equal(rew[j].cpu().numpy(), ora.reward), (where, j)
+                    assert np.array_equal(term[j].cpu().numpy(), ora.terminated), (where, j)
         elif kind == "random":
             if not auto_reset:
                 continue
@@ -168,6 +190,7 @@ def one_case(case):
             other.load_state_dict(blob)
             eng.close()
             eng = other
+            replay_bufs = replay_plan = None                             # (a plan belongs to the engine it was made for)
             assert eng.last_records_enabled == keep_last, where          # travels with the state blob
             eng.set_illegal_move_reward(irw)
             eng.set_max_tile(max_tile)
