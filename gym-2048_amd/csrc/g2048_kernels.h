@@ -72,11 +72,10 @@ struct StatsOut {
 hipError_t launch_reset(const StepArgs &a, uint32_t first_slot, const uint8_t *mask, hipStream_t s);
 hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s);
 hipError_t launch_rollout_random(const StepArgs &a, hipStream_t s);
-// a k-step launch train as a cached hipGraph: [set clock] -> k x step (t read from *t_dev); see g2048_kernels.hip
+// a k-step launch train as a cached hipGraph: k x step (t read from *t_dev, written by a launch in front); see g2048_kernels.hip
 struct RolloutGraph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    hipGraphNode_t set_node = nullptr;
     unsigned long long *t_dev = nullptr;
 };
 bool rollout_graph_supported(const StepArgs &a); // the standard configuration: reward + terminated, nothing optional, spawn stream

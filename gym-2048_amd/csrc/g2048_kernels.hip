@@ -553,7 +553,7 @@ step_kernel(uint4 *boards, const void *actions, unsigned long long *ep_counters,
 // The same step with the transaction counter read from DEVICE MEMORY: t = *t_ptr + j.  This is the node of a CACHED
 // hipGraph of a k-step launch train (launch_rollout_graph below): the graph's kernel arguments are frozen when it is
 // built, so everything that differs between two rollouts over the same buffers -- only t -- comes through memory, written
-// by the one-lane set_clock_kernel node in front of the train.  Standard configuration only (reward + terminated, no
+// by a one-lane set_clock_kernel launch in front of the graph.  Standard configuration only (reward + terminated, no
 // optional output).  The s_load of t (uniform address, scalar cache) is in flight together with the board load.
 __global__ void __launch_bounds__(64) set_clock_kernel(unsigned long long *t_ptr, unsigned long long value)
 {
@@ -1498,9 +1498,8 @@ hipError_t launch_reset_numpy(const StepArgs &a, const uint8_t *mask, hipStream_
 // At 65 536 boards a step kernel takes ~2.4 us on the device and one host thread issues a launch every 3.0-4.6 us: the
 // per-step path is host-issue-bound (tools/ubench/r5_probe.hip: 3.0-4.6 us per step by stream launches, 2.43-2.45 us as a
 // graph replay; 2^17 boards 2.9-3.6 vs 2.95-2.99; from 2^18 boards on the kernel is the longer of the two and the forms tie).
-// The graph is [set_clock_kernel] -> k x step_graph_kernel, explicit nodes in a chain; building and instantiating it costs
-// ~1.8 us per node (less than launching the same train once), replaying it one hipGraphExecKernelNodeSetParams (the new
-// clock value, 2.5 us) + one hipGraphLaunch.
+// The graph is k x step_graph_kernel, explicit nodes in a chain; building and instantiating it costs ~1.8 us per node (less
+// than launching the same train once), replaying it one set_clock_kernel launch (the new clock value) + one hipGraphLaunch.
 bool rollout_graph_supported(const StepArgs &a)
 {
     return a.n != 0 && a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0 && !a.boards_out &&
@@ -1530,7 +1529,6 @@ void destroy_rollout_graph(RolloutGraph &g)
         (void)hipGraphDestroy(g.graph);
     g.exec = nullptr;
     g.graph = nullptr;
-    g.set_node = nullptr;
 }
 
 // `first`: the arguments of step 0 (its t is ignored); step j reads / writes its I/O j * stride elements further on.
@@ -1546,15 +1544,7 @@ hipError_t build_rollout_graph(const StepArgs &first, int action_dtype, uint32_t
     hipError_t err = hipGraphCreate(&g.graph, 0);
     if (err != hipSuccess)
         return err;
-    unsigned long long value = 0;
-    void *set_args[2] = {&g.t_dev, &value};
-    hipKernelNodeParams sp{};
-    sp.func = reinterpret_cast<void *>(set_clock_kernel);
-    sp.gridDim = dim3(1);
-    sp.blockDim = dim3(64);
-    sp.kernelParams = set_args;
-    err = hipGraphAddKernelNode(&g.set_node, g.graph, nullptr, 0, &sp);
-    hipGraphNode_t prev = g.set_node;
+    hipGraphNode_t prev = nullptr;
     for (uint32_t j = 0; j < k_steps && err == hipSuccess; ++j) {
         const size_t off = static_cast<size_t>(j) * stride;
         uint4 *boards = first.st.boards;
@@ -1572,7 +1562,7 @@ hipError_t build_rollout_graph(const StepArgs &first, int action_dtype, uint32_t
         kp.blockDim = dim3(kBlock);
         kp.kernelParams = args;
         hipGraphNode_t node = nullptr;
-        err = hipGraphAddKernelNode(&node, g.graph, &prev, 1, &kp);
+        err = hipGraphAddKernelNode(&node, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
         prev = node;
     }
     if (err == hipSuccess)
@@ -1585,16 +1575,13 @@ hipError_t build_rollout_graph(const StepArgs &first, int action_dtype, uint32_t
     return hipSuccess;
 }
 
-// Replay: step j of the train plays transaction t_first + j.
+// Replay: step j of the train plays transaction t_first + j.  The clock is written by an ORDINARY launch in front of the
+// graph -- its value is captured when it is enqueued, so two replays enqueued back to back each see their own (an executable
+// graph's node parameters must not be rewritten while an earlier launch of it may still be waiting to run).
 hipError_t launch_rollout_graph(RolloutGraph &g, unsigned long long t_first, hipStream_t s)
 {
-    void *set_args[2] = {&g.t_dev, &t_first};
-    hipKernelNodeParams sp{};
-    sp.func = reinterpret_cast<void *>(set_clock_kernel);
-    sp.gridDim = dim3(1);
-    sp.blockDim = dim3(64);
-    sp.kernelParams = set_args;
-    hipError_t err = hipGraphExecKernelNodeSetParams(g.exec, g.set_node, &sp);
+    hipLaunchKernelGGL(set_clock_kernel, dim3(1), dim3(64), 0, s, g.t_dev, t_first);
+    const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
         return err;
     return hipGraphLaunch(g.exec, s);

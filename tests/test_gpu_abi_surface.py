@@ -516,6 +516,28 @@ def test_small_batch_rollouts_are_replayed_from_a_cached_graph(torch_cuda, monke
                 assert np.array_equal(r[j].cpu().numpy(), twin.reward) and np.array_equal(t[j].cpu().numpy(), twin.terminated), (rep, q, j)
     assert pre.graph_replays == 8
     assert np.array_equal(pre.get_boards().reshape(n, 16), twin.boards) and np.array_equal(pre.get_scores(), twin.score)
+    # replays enqueued BACK TO BACK, nothing synchronised in between -- the same graph twice and all four in a row: every
+    # replay must see its own clock (it is written by an ordinary launch in front of each graph launch, not by rewriting
+    # the executable graph's parameters under an earlier launch's feet)
+    with torch.cuda.stream(stream):
+        plans[0].run()
+        first = bufs[0][0].clone()
+        plans[0].run()
+        for q in (1, 2, 3):
+            plans[q].run()
+    stream.synchronize()
+    assert pre.graph_replays == 13
+    want = []
+    for _ in range(5):
+        rows = []
+        for j in range(k):
+            twin.step(None)
+            rows.append(twin.reward.copy())
+        want.append(np.stack(rows))
+    assert np.array_equal(first.cpu().numpy(), want[0]) and np.array_equal(bufs[0][0].cpu().numpy(), want[1])
+    for q in (1, 2, 3):
+        assert np.array_equal(bufs[q][0].cpu().numpy(), want[1 + q]), q
+    assert np.array_equal(pre.get_boards().reshape(n, 16), twin.boards) and np.array_equal(pre.get_scores(), twin.score)
     pre.close()
 
 
