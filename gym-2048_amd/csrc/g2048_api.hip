@@ -814,7 +814,8 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
                     ++e->graph_replays;
                     return G2048_OK;
                 }
-                // nothing was enqueued (the launch of a graph is all or nothing): fall through to stream launches
+                // no step was enqueued (the launch of a graph is all or nothing; at most the one-lane clock write went out,
+                // which nobody else reads): fall through to stream launches
                 (void)hipGetLastError();
                 g2048::destroy_rollout_graph(have->g);
                 e->graph_enabled = 0;

@@ -219,7 +219,14 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
  * highest priority -- the side stream's own: two streams of one priority may be given one hardware queue, and the ticket
  * kernels need two) runs as one chain; g2048_get_chains_used tells
  * what the most recent g2048_rollout did.  Engines of one device share the side chain: their rollouts take turns on it.
- * Default: 1. */
+ * Default: 1 -- the form is OPT-IN: it starts a launch thread per device (which spins for G2048_SIDE_SPIN_US microseconds,
+ * default 200, after a job before it sleeps; rollouts of fewer than 6 steps leave it asleep) and can only ever fire for a
+ * single g2048_rollout of >= 12 steps whose actions are all supplied up front -- never for a caller that steps one action
+ * at a time.  The knobs (G2048_TWO_CHAIN_MIN_STEPS, G2048_CHAIN_SYNC, G2048_CHAIN_ANY_PRIORITY, G2048_FLAG_WAIT_POLLS) are
+ * read by THIS call, once.  Failure behaviour: a ticket wait is bounded (2^26 polls of ~1 us); one that runs out reports
+ * through pinned host memory and EVERY later call on the engine returns G2048_ERR_HIP (its chains ran unordered); a
+ * rollout whose launches fail half-way still enqueues its join and leaves the engine refusing further calls.  A profiler
+ * that serialises kernels across queues (rocprofv3 --pmc) makes the tickets wait for each other: use one chain there. */
 int g2048_set_chains(g2048_engine *e, int chains);
 int g2048_get_chains(const g2048_engine *e);
 int g2048_get_chains_used(const g2048_engine *e);
