@@ -66,7 +66,10 @@ int64_t steady_now_ns()
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr uint64_t kStateMagic = 0x3376383430324700ull; // "\0G2048v3": layout 3 = records carry the score, 4-word episode slots
+// "\0G2048v4": layout as v3 (records carry the score, 4-word episode slots); the version moved with the spawn rule of ABI 14
+// (g2048.h "Randomness"): a game saved under the old rule would continue differently under the new one, so a v3 blob is
+// refused instead of silently resumed.
+constexpr uint64_t kStateMagic = 0x3476383430324700ull;
 
 } // namespace
 
@@ -1631,8 +1634,10 @@ int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, 
     StateHeader h;
     std::memcpy(&h, host_buf, sizeof h);
     if (h.magic != kStateMagic || h.n != e->n)
-        return fail(G2048_ERR_INVALID, "state blob does not match this engine (magic %llx, n %llu vs %llu)",
-                    (unsigned long long)h.magic, (unsigned long long)h.n, (unsigned long long)e->n);
+        return fail(G2048_ERR_INVALID, "state blob does not match this engine (magic %llx%s, n %llu vs %llu)",
+                    (unsigned long long)h.magic, h.magic == 0x3376383430324700ull ? " = a blob written before ABI 14: its games were played "
+                    "under the old spawn rule and cannot be continued under this one" : "",
+                    (unsigned long long)h.n, (unsigned long long)e->n);
     const uint64_t want = sizeof(StateHeader) + e->slab_bytes + ((h.reserved & 1u) ? e->n * 40 : 0);
     if (blob_bytes != want)
         return fail(G2048_ERR_INVALID, "state blob is %llu bytes, this engine's state is %llu",

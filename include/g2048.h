@@ -355,7 +355,8 @@ int g2048_augment(const uint8_t *boards, const uint8_t *next_boards, const uint8
  * only models; its env state hooks are get_board/set_board (game2048_env.py:282-288). */
 uint64_t g2048_state_bytes(const g2048_engine *e);
 int g2048_get_state(const g2048_engine *e, void *host_buf, void *stream);
-/* blob_bytes = size of host_buf; magic, board count, size and header fields are validated. */
+/* blob_bytes = size of host_buf; magic, board count, size and header fields are validated.  Blobs written before ABI 14
+ * are refused (their games were played under the previous spawn rule). */
 int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, void *stream);
 
 /* Symmetric-board canonicalisation (the counterpart of g2048_augment): every board (plain uint8[n][16]

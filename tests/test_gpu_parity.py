@@ -515,6 +515,13 @@ def test_argument_validation_on_device(torch_cuda):
         Batched2048(8, rng="mt19937")
     with pytest.raises(ValueError):
         e.load_state_dict({"blob": np.zeros(10, np.uint8)})
+    # a blob written before ABI 14 ("\0G2048v3") was played under the previous spawn rule: refused, with the reason
+    from gym2048_amd._lib import G2048Error
+    old = e.state_dict()
+    assert bytes(old["blob"][:8]) == b"\0G2048v4"
+    old["blob"][7] = ord("3")
+    with pytest.raises(G2048Error, match="before ABI 14"):
+        e.load_state_dict(old)
     boards = e.get_boards()
     e.step(torch.full((128,), 7, dtype=torch.int64))            # only the low two bits count: 7 == left
     f = Batched2048(128, seed=1)
