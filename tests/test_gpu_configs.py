@@ -310,6 +310,32 @@ def test_bench_gpus_2_launches_itself(torch_cuda, gather):
     print(f"self-launched 2 ranks ({gather}): {line['value']:.3e} env-steps/s, timing {t}")
 
 
+def test_bench_under_torch_distributed_run(torch_cuda):
+    """The OTHER launch form of the contract -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with N = 2 on the one GPU (both ranks on cuda:0, gloo):
+    the launcher's RANK / LOCAL_RANK / WORLD_SIZE are used as they come, all ranks share one stdout and rank 0's JSON line must
+    still be its LAST line."""
+    import json
+    import socket
+    env = dict(os.environ, G2048_BENCH_BACKEND="gloo", G2048_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "G2048_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--no-extras", "--boards", "131072", "--device-warmup", "0.05"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), lines[-3:]
+    line = json.loads(lines[-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["pg_world_size"] == 2 and cfg["gathered_rows"] == 2 and cfg["backend"] == "gloo"
+    assert cfg["global_boards"] == 2 * 131072 and cfg["chains"] == 1 and line["value"] > 1e7
+
+
 def test_bench_gpus_8_rehearsal_on_one_device(torch_cuda):
     """The driver's 8-GPU scaling command -- `python bench.py --gpus 8 --steps 20 --warmup 5` -- rehearsed end to end on
     the one GPU there is: eight processes on cuda:0 (G2048_BENCH_SAME_DEVICE=1), gloo carrying the collectives (RCCL

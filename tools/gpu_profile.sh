@@ -34,7 +34,7 @@ grep -h '"metric"' $O/stats2.log > $O/bench_two_chains_under_rocprof.json
 # kernel-trace statistics of every kernel, and the HBM traffic counters of the step kernel that writes observations
 # (one chain: counter collection serialises kernels ACROSS queues, so the ticket kernels of a two-chain rollout would wait
 #  for each other until their bound runs out -- loudly, since round 5)
-BENCHX="python bench.py --chains 1 --steps 200 --warmup 20 --cpu-seconds 1 $*"
+BENCHX="python bench.py --chains 1 --no-two-chain-extra --steps 200 --warmup 20 --cpu-seconds 1 $*"
 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/statsx -o r -- $BENCHX > $O/statsx.log 2>&1
 cp $O/statsx/r_kernel_stats.csv $O/kernel_stats_extras.csv 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcx_fetch -o r -- $BENCHX > $O/pmcx_fetch.log 2>&1
