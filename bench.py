@@ -5,11 +5,12 @@
 
 A "step" is one pass of the hot path over the whole batch: step_kernel advances every board by one action
 (move + score + spawn + done + auto-reset), reading the action from, and writing reward/terminated to, [K][B]
-rollout buffers that are resident in HBM before the timed region starts.  With --chains 2 (default) the pass is TWO
-launches per rank, one per half of the batch, run as two chains on two streams from two host threads
-(g2048_set_chains: bit-identical to one chain; the head of one half-batch kernel overlaps the tail of the other's);
-with --chains 1 it is ONE launch on one stream.  Workload = BASELINE configs[2]: B = 2^20 boards per GPU, synthetic uniform
-random policy (actions pre-generated on the device by g2048_fill_random_actions), seed 42.
+rollout buffers that are resident in HBM before the timed region starts.  The launch form is chosen by K ALONE, the same
+for every N: below 200 steps the pass is ONE launch on one stream (--chains 1); from 200 steps it is TWO launches per rank,
+one per half of the batch, run as two chains on two streams from two host threads (g2048_set_chains(2): bit-identical to
+one chain; the head of one half-batch kernel overlaps the tail of the other's); --chains overrides, `config.chains` says
+what the timed rollout did.  Workload = BASELINE configs[2]: B = 2^20 boards per GPU, synthetic uniform random policy
+(actions pre-generated on the device by g2048_fill_random_actions), seed 42.
 
 N > 1, one rank per GPU: either under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or as plain `python bench.py --gpus N ...`, which
@@ -29,10 +30,14 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- algorithmic bytes (38 B/env-step) / HIP-event time per launch vs the 8 TB/s HBM peak;
                   `traffic` = HBM bytes per launch from the committed PMC profile, printed only while the
                   profile was taken from the kernel sources that are being run (hash of csrc/), else null
-  cpu_baseline -- the C oracle (oracle/, "port") timed on this box's host cores on a bounded sample
-  extras       -- a 2^24-board run that really streams HBM (best of 4), the step that writes its one-hot observation
-                  (one launch), the policy-in-the-loop figure (BASELINE configs[4]), fused rollout kernels,
-                  numpy-RNG mode, the single-env host path, Python port
+  cpu_baseline -- the C oracle (oracle/, "port") timed on this box's host cores on a bounded sample; reference_estimate =
+                  the Python port's rate here / the port-to-reference ratio measured in the build container
+  timing       -- the split of the region, and k_region_repeats_us: five further regions with the same brackets
+                  (`value` is the FIRST region)
+  extras       -- the other launch form (two_chains_k200 / single_chain), BASELINE configs[1] (batch_65536), a 2^24-board
+                  run that really streams HBM (best of 4), the step that writes its one-hot observation (one launch), the
+                  policy-in-the-loop figure (BASELINE configs[4]), fused rollout kernels, numpy-RNG mode, the single-env host
+                  path, Python port
 """
 from __future__ import annotations
 
