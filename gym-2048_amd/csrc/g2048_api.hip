@@ -377,6 +377,12 @@ int g2048_destroy(g2048_engine *e)
             (void)hipEventDestroy(e->fork_event);
         if (e->join_event)
             (void)hipEventDestroy(e->join_event);
+        bool any_graph = false;
+        for (auto &entry : e->graphs)
+            any_graph = any_graph || entry.g.exec;
+        if (any_graph)
+            (void)hipDeviceSynchronize(); // a replay may still be running: an executable graph is destroyed only at rest (the
+                                          // hipFree of the slab below waits for the device anyway)
         for (auto &entry : e->graphs)
             g2048::destroy_rollout_graph(entry.g);
         if (e->graph_t_dev)
@@ -692,6 +698,8 @@ static g2048_engine::GraphEntry *build_graph(g2048_engine *e, const g2048_engine
 {
     g2048_engine::GraphEntry *slot = &e->graphs[e->graph_next];
     e->graph_next = (e->graph_next + 1) % g2048_engine::kGraphSlots;
+    if (slot->g.exec)
+        (void)hipDeviceSynchronize(); // evicting a graph that may still be replaying (a fifth set of buffers: rare)
     g2048::destroy_rollout_graph(slot->g);
     hipError_t err = hipSuccess;
     if (!e->graph_t_dev) {
