@@ -396,6 +396,21 @@ def main():
     #      loses that state within a few hundred microseconds of idling (tools/ubench/gap_probe.hip: a 20-launch train
     #      takes 199.8 us right after a synchronize, 207.7 us after 0.5 ms of idle, 210.8 us after 2 ms) -- and the
     #      scratch engine is only freed after the timed region (hipFree synchronises the device).
+    # Host hygiene for a 200 us region that the HOST feeds (20 launches of ~3 us each, then a poll): no cyclic garbage
+    # collection inside it (what timeit does) -- collected NOW, before the device warm-up, because a full collection takes
+    # milliseconds and nothing but launches may stand between the warm-up and the timed region -- and, where the process
+    # may, a scheduling priority that a neighbour's batch job on the same host cannot push aside (one of eleven driver-style
+    # runs of round 5 had every region stretched to 230-470 us by a host that issued a launch every 15 us instead of every
+    # 3: profiles/r05_h_bench_k20_outlier.json).
+    import gc
+    gc.collect()
+    gc.disable()
+    host_priority = None
+    try:
+        os.setpriority(os.PRIO_PROCESS, 0, -10)
+        host_priority = os.getpriority(os.PRIO_PROCESS, 0)
+    except (OSError, AttributeError):
+        pass
     scratch = None
     if args.device_warmup > 0:
         scratch = Batched2048(B, device=local_rank, seed=SEED + 1, last_records=keep_last, chains=args.chains)   # same configuration
@@ -445,19 +460,6 @@ def main():
             after_us = 0.0
         return wall, ev0.elapsed_time(ev1), (ev1.elapsed_time(ev2) if dist_on else 0.0), rows, after_us
 
-    # Host hygiene for a 200 us region that the HOST feeds (20 launches of ~3 us each, then a poll): no cyclic garbage
-    # collection inside it (what timeit does), and -- where the process may -- a scheduling priority that a neighbour's
-    # batch job on the same host cannot push aside (one of eleven driver-style runs of round 5 had every region stretched to
-    # 230-470 us by a host that issued a launch every 15 us instead of every 3: profiles/r05_h_bench_k20_outlier.json).
-    import gc
-    gc.collect()
-    gc.disable()
-    host_priority = None
-    try:
-        os.setpriority(os.PRIO_PROCESS, 0, -10)
-        host_priority = os.getpriority(os.PRIO_PROCESS, 0)
-    except (OSError, AttributeError):
-        pass
     for wp in wplans:                                    # the W untimed warm-up steps of the benchmarked engine
         wp.run()
     elapsed, kernel_region_ms, collective_ms, gathered, sync_after_us = timed_region()   # THE timed region: `value`
