@@ -19,7 +19,7 @@ def test_cited_profile_files_exist():
     missing = []
     for doc in ("DESIGN.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "README.md")):
         text = open(os.path.join(ROOT, doc), encoding="utf-8").read()
-        for m in re.finditer(r"`((?:r0[1-9]|traffic)_[A-Za-z0-9_*.…]+)`", text):
+        for m in re.finditer(r"`(?:profiles/)?((?:r0[1-9]|traffic)_[A-Za-z0-9_*.…]+)`", text):
             name = m.group(1).rstrip(".")
             if "…" in name:
                 continue
