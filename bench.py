@@ -535,6 +535,7 @@ def main():
                    # wall us per region, and their launch trains -- `value` stays the FIRST region
                    "k_region_repeats_us": [r[0] * 1e6 for r in repeats],
                    "k_region_repeats_launch_train_us": [r[1] * 1e3 for r in repeats],
+                   "k_region_repeats_collective_us": [r[2] * 1e3 for r in repeats],
                    "k_region_first_us": elapsed * 1e6,
                    "host": {"gc": "disabled for the timed regions", "nice": host_priority}},
         "episodes_finished": int(stats["episodes"]), "return_sum": int(stats["return_sum"]),
