@@ -315,7 +315,7 @@ def main():
     if dist_on:
         dist.barrier()
     from gym2048_amd.batched import Batched2048
-    from gym2048_amd.sharding import weak_shard, allgather_returns, allgather_stats, merge_stats
+    from gym2048_amd.sharding import weak_shard, allgather_returns, allgather_stats, merge_stats, SummaryExchange
 
     B, K, W = args.boards, args.steps, args.warmup
     shard = weak_shard(B, rank, world)
@@ -356,15 +356,28 @@ def main():
     stats_buf = torch.empty(stats_bytes, dtype=torch.uint8, device=dev)
     returns_buf = torch.empty(B, dtype=torch.int32, device=dev) if args.gather == "full" else None
 
+    # How the summaries travel (config.collective_path): "direct" = the library's own communicator,
+    # g2048_allgather_summary -- ONE summary launch writing into this rank's row + ONE in-place ncclAllGather, both on the
+    # launch stream; "torch" = g2048_returns_summary_async + torch.distributed.all_gather_into_tensor (ProcessGroupNCCL
+    # hops to its own stream and back).  A/B on one GPU under G2048_BENCH_FORCE_DIST: profiles/r06_*_forced_dist_ab.txt.
+    collective_path = os.environ.get("G2048_BENCH_COLLECTIVE", "direct")
+    if collective_path not in ("direct", "torch"):
+        sys.exit("G2048_BENCH_COLLECTIVE must be 'direct' or 'torch'")
+    if not dist_on or backend != "nccl" or args.gather != "summary":
+        collective_path = "torch"                        # gloo smoke tests (host copies) and --gather full
+    exchange = SummaryExchange(eng) if (dist_on and collective_path == "direct") else None
+
     def gather_returns():
         """The path's only exchange, once per rollout: every rank reduces the episodic returns of its shard on
-        the device (one kernel pair, no host sync: episodes, illegal ends and the EXACT sum of the final scores of all
+        the device (ONE launch, no host sync: episodes, illegal ends and the EXACT sum of the final scores of all
         finished episodes, g2048_stats.return_sum) and the per-rank summaries are all-gathered (RCCL over xGMI,
         latency-bound); --gather full ships every board's last return instead (4 MiB per rank at 2^20).
         Everything is enqueued on the current stream into buffers allocated beforehand."""
         if args.gather == "full":
             local = eng.last_scores(out=returns_buf)     # int32[B] returns, from the terminal records (one kernel)
             return allgather_returns(local.cpu() if host_gather else local, shard)
+        if exchange is not None:
+            return exchange.gather()
         local = eng.episode_stats_device(out=stats_buf, returns_only=True)
         return allgather_stats(local.cpu() if host_gather else local)
 
@@ -515,6 +528,10 @@ def main():
                    "backend": (backend if dist_on else None),
                    "pg_world_size": (dist.get_world_size() if dist_on else 1),
                    "gathered_rows": gathered_rows,
+                   "collective_path": ((("g2048_allgather_summary: one summary launch + one in-place ncclAllGather on the launch stream"
+                                         if collective_path == "direct" else
+                                         "g2048_returns_summary_async + torch.distributed.all_gather_into_tensor") if args.gather == "summary"
+                                        else "g2048_get_last_scores + torch.distributed.all_gather_into_tensor") if dist_on else None),
                    "collective": ((f"one all-gather per rollout of the per-rank return summaries (g2048_stats, {stats_bytes} B each)"
                                    if args.gather == "summary" else "one all-gather per rollout of the per-board episodic returns (int32[B] each)")
                                   if dist_on else "none")},
@@ -858,6 +875,8 @@ def main():
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if exchange is not None:
+        exchange.close()
     if dist_on:
         dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libg2048_hip.so")
 
 ACT_RANDOM, ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2, 3
 OBS_U8, OBS_F16, OBS_F32 = 0, 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class G2048Error(RuntimeError):
@@ -80,6 +80,8 @@ SIGNATURES = {
     "g2048_num_boards": (_u64, [_E]),
     "g2048_set_illegal_move_reward": (C.c_int, [_E, C.c_float]),
     "g2048_set_max_tile": (C.c_int, [_E, C.c_int]),
+    "g2048_set_strict_actions": (C.c_int, [_E, C.c_int]),
+    "g2048_get_strict_actions": (C.c_int, [_E]),
     "g2048_reset": (C.c_int, [_E, C.c_int, _u32, C.c_void_p, _S]),
     "g2048_step": (C.c_int, [_E, C.POINTER(StepIO), C.c_int, _S]),
     "g2048_host_io_map": (C.c_int, [_E, C.POINTER(HostIO)]),
@@ -125,6 +127,9 @@ SIGNATURES = {
     "g2048_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "g2048_comm_destroy": (C.c_int, [C.c_void_p]),
     "g2048_allgather_returns": (C.c_int, [_E, C.c_void_p, C.c_void_p, _S]),
+    "g2048_allgather_summary": (C.c_int, [_E, C.c_void_p, C.c_void_p, _S]),
+    "g2048_comm_world": (C.c_int, [C.c_void_p]),
+    "g2048_comm_rank": (C.c_int, [C.c_void_p]),
     "g2048_comm_local_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "g2048_comm_local_destroy": (C.c_int, [C.c_void_p]),
     "g2048_allgather_returns_local": (C.c_int, [C.c_void_p, C.POINTER(_E), C.POINTER(C.c_void_p), C.POINTER(_S)]),

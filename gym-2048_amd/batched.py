@@ -75,7 +75,7 @@ class Batched2048:
 
     def __init__(self, n_envs: int, device: int = 0, seed: int = 0, board_offset: int = 0,
                  illegal_move_reward: float = 0.0, max_tile=None, rng: str = "philox", last_records: bool = True,
-                 chains=None):
+                 chains=None, strict_actions: bool = False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         if not torch.cuda.is_available():
@@ -112,6 +112,8 @@ class Batched2048:
             chains = 1
         if chains != 1:
             self.set_chains(chains)
+        if strict_actions:
+            self.set_strict_actions(True)
         if self.rng_mode == "numpy":
             self.seed(seed)
         # The engine may be used from ANY stream once the constructor has returned: what was enqueued here (the fills of
@@ -150,6 +152,17 @@ class Batched2048:
         exp = max_tile_to_exp(max_tile)
         self.max_tile = max_tile
         check(self._lib.g2048_set_max_tile(self._h, exp))
+
+    def set_strict_actions(self, enable: bool):
+        """``g2048_set_strict_actions``: with it on, a step / rollout whose action tensor holds a value outside 0..3
+        (game2048_env.py:49 declares ``Discrete(4)``; :210-212 would play 4 as "down", this library plays the low two bits)
+        still runs, but the NEXT call on the engine after that launch has completed raises ``G2048Error`` once; host-array
+        steps (``step_host`` / ``step_numpy``) are refused before anything is stepped.  Default off."""
+        check(self._lib.g2048_set_strict_actions(self._h, int(bool(enable))))
+
+    @property
+    def strict_actions(self) -> bool:
+        return bool(self._lib.g2048_get_strict_actions(self._h))
 
     def set_last_records(self, enable: bool):
         """Keep (default) or stop keeping the terminal record of every board's most recent finished episode
@@ -701,7 +714,7 @@ def parse_stats(raw) -> dict:
     # last_score_max == -1: the terminal records were not read (a returns-only summary, or an engine that does not keep
     # them) -- the last_* keys are then None, not a measured 0
     known = st.last_score_max >= 0
-    return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_count=st.last_count if known else None,
+    return dict(episodes=st.episodes, illegal_ends=st.illegal_ends, last_known=known, last_count=st.last_count if known else None,
                 last_score_sum=st.last_score_sum if known else None, last_score_max=st.last_score_max if known else None,
                 max_exp=st.max_exp,
                 mean_last_score=((st.last_score_sum / st.last_count) if st.last_count else 0.0) if known else None,

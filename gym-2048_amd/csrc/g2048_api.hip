@@ -87,6 +87,7 @@ struct g2048_engine {
     g2048::DeviceState st{};
     g2048::StatsOut *stats_dev = nullptr;
     unsigned long long *stats_partials = nullptr; // stage-1 output of the statistics reduction
+    unsigned long long *summary_scratch = nullptr; // partials + "last one out" counters of the one-launch returns summary (in the slab: zero)
     void *scratch = nullptr; // staging for host-side get/set of boards and scores (16 B per board), lazily
     // host-resident I/O (g2048_host_io_map): one block of pinned, device-mapped, coherent host memory
     void *host_base = nullptr;
@@ -146,6 +147,10 @@ struct g2048_engine {
     uint32_t graph_max_boards = 1u << 17; // batches up to this size use the form (G2048_GRAPH_MAX_BOARDS, read by g2048_create)
     int graph_enabled = 1;              // G2048_ROLLOUT_GRAPH=0 (read by g2048_create) turns the form off; a failing graph call too
     uint64_t graph_replays = 0;         // rollouts served from the cached graph (g2048_get_graph_replays)
+    // strict actions (g2048_set_strict_actions): 64 bytes of pinned, coherent host memory a step kernel reports an action
+    // outside 0..3 to; read (and cleared) at the entry of the next call on the engine
+    int strict_actions = 0;
+    unsigned long long *action_err_host = nullptr, *action_err_dev = nullptr;
     int track_last = 1;   // keep the terminal record of every board's most recent finished episode (g2048_set_last_records)
     int32_t *returns = nullptr; // send buffer of the all-gather (int32[n]), lazily; NOT the staging buffer: a collective
                                 // in flight on one stream must not be clobbered by a get_* call on another
@@ -180,6 +185,7 @@ g2048::StepArgs make_args(const g2048_engine *e, const g2048_step_io *io, int au
         a.obs_dtype = static_cast<uint32_t>(io->obs_dtype);
         a.boards_out = reinterpret_cast<uint4 *>(io->boards_out);
     }
+    a.action_err = e->strict_actions ? e->action_err_dev : nullptr;
     a.n = static_cast<uint32_t>(e->n);
     a.board_offset = static_cast<uint32_t>(e->board_offset);
     a.seed_lo = static_cast<uint32_t>(e->seed);
@@ -224,6 +230,17 @@ int usable(const g2048_engine *e)
                                    "(%u polls of ~1 us): its chains ran unordered from there on, the engine's boards and "
                                    "the rollout's outputs are undefined -- destroy the engine",
                     __atomic_load_n(e->chain_err_host, __ATOMIC_ACQUIRE), e->chain_wait_polls);
+    if (e->action_err_host) {
+        // strict actions: a step kernel that has COMPLETED by now saw an action outside 0..3.  Reported once, by this call
+        // (which does nothing else), and cleared; the step itself played the action's low two bits.
+        const unsigned long long w = __atomic_exchange_n(e->action_err_host, 0ull, __ATOMIC_ACQ_REL);
+        if (w != 0ull)
+            return fail(G2048_ERR_INVALID, "strict actions: an earlier step was given an action outside 0..3 (e.g. global board %u, "
+                                           "low byte 0x%02x); that step played the action's low two bits (the reference, "
+                                           "game2048_env.py:210-212, would have played 4 as 'down' and -1 as 'right').  "
+                                           "This call did nothing; the report is cleared",
+                        static_cast<unsigned>(w & 0xffffffffull), static_cast<unsigned>((w >> 32) & 0xffu));
+    }
     return G2048_OK;
 }
 
@@ -273,7 +290,7 @@ extern "C" {
 
 const char *g2048_last_error(void) { return g_error; }
 
-int g2048_abi_version(void) { return 14; }
+int g2048_abi_version(void) { return 15; }
 
 int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_offset, g2048_engine **out)
 {
@@ -315,7 +332,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     // one slot of kSlotWords counters per 64 boards (whole 256-lane launch blocks)
     const size_t n_counters = ((n + 255) / 256) * 4 * g2048::kSlotWords;
     const size_t off_stats = off_counters + align_up(n_counters * sizeof(unsigned long long));
-    e->slab_bytes = off_stats + align_up(sizeof(g2048::StatsOut));
+    const size_t off_summary = off_stats + align_up(sizeof(g2048::StatsOut));
+    e->slab_bytes = off_summary + align_up(g2048::kSummaryScratchWords * sizeof(unsigned long long));
     err = hipMalloc(&e->slab, e->slab_bytes);
     if (err != hipSuccess) {
         const size_t wanted = e->slab_bytes;
@@ -344,6 +362,7 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     e->st.last_record = reinterpret_cast<uint4 *>(base + off_last_record);
     e->st.ep_counters = reinterpret_cast<unsigned long long *>(base + off_counters);
     e->stats_dev = reinterpret_cast<g2048::StatsOut *>(base + off_stats);
+    e->summary_scratch = reinterpret_cast<unsigned long long *>(base + off_summary);
     *out = e;
     return G2048_OK;
 }
@@ -391,6 +410,8 @@ int g2048_destroy(g2048_engine *e)
             (void)hipFree(e->chain_flags);
         if (e->chain_err_host)
             (void)hipHostFree(e->chain_err_host);
+        if (e->action_err_host)
+            (void)hipHostFree(e->action_err_host);
         if (e->st.rng)
             (void)hipFree(e->st.rng);
         if (e->scratch)
@@ -469,6 +490,31 @@ int g2048_set_illegal_move_reward(g2048_engine *e, float reward)
     e->illegal_reward = reward;
     return G2048_OK;
 }
+
+int g2048_set_strict_actions(g2048_engine *e, int enable)
+{
+    if (int rc = usable(e))
+        return rc;
+    if (enable && !e->action_err_host) {
+        G2048_HIP(hipSetDevice(e->device));
+        void *host = nullptr, *dev = nullptr;
+        hipError_t err = hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (err != hipSuccess)
+            return fail(G2048_ERR_NOMEM, "hipHostMalloc(64) for the action error word failed: %s", hipGetErrorString(err));
+        err = hipHostGetDevicePointer(&dev, host, 0);
+        if (err != hipSuccess) {
+            (void)hipHostFree(host);
+            return fail(G2048_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(err));
+        }
+        std::memset(host, 0, 64);
+        e->action_err_host = static_cast<unsigned long long *>(host);
+        e->action_err_dev = static_cast<unsigned long long *>(dev);
+    }
+    e->strict_actions = enable ? 1 : 0;
+    return G2048_OK;
+}
+
+int g2048_get_strict_actions(const g2048_engine *e) { return e ? e->strict_actions : 0; }
 
 int g2048_set_max_tile(g2048_engine *e, int max_exp)
 {
@@ -1210,6 +1256,14 @@ int g2048_step_host(g2048_engine *e, int auto_reset, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = refuse_capture(s, "g2048_step_host"))
         return rc;
+    if (e->strict_actions) { // the actions are HOST memory here: refused before anything is stepped
+        const int64_t *acts = e->host_io.actions;
+        for (uint64_t i = 0; i < e->n; ++i)
+            if (acts[i] < 0 || acts[i] > 3)
+                return fail(G2048_ERR_INVALID, "strict actions: action %lld of board %llu is outside 0..3 (game2048_env.py:49 "
+                                               "Discrete(4)); nothing was stepped",
+                            static_cast<long long>(acts[i]), static_cast<unsigned long long>(e->board_offset + i));
+    }
     const g2048_host_io &d = e->host_io_dev;
     g2048_step_io io{};
     io.actions = d.actions;
@@ -1497,7 +1551,7 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream)
         return fail(G2048_ERR_INVALID, "NULL argument");
     G2048_HIP(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, e->stats_dev, false, s));
+    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, e->summary_scratch, e->stats_dev, false, s));
     g2048::StatsOut h{};
     G2048_HIP(hipMemcpyAsync(&h, e->stats_dev, sizeof h, hipMemcpyDeviceToHost, s));
     G2048_HIP(hipStreamSynchronize(s));
@@ -1523,7 +1577,8 @@ static int stats_async(const g2048_engine *e, g2048_stats *device_out, bool retu
     if (!is_device_ptr(device_out))
         return fail(G2048_ERR_INVALID, "the asynchronous statistics need a DEVICE buffer (use g2048_episode_stats for a host struct)");
     G2048_HIP(hipSetDevice(e->device));
-    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, reinterpret_cast<g2048::StatsOut *>(device_out),
+    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, e->summary_scratch,
+                                  reinterpret_cast<g2048::StatsOut *>(device_out),
                                   returns_only, static_cast<hipStream_t>(stream)));
     return G2048_OK;
 }
@@ -1840,6 +1895,31 @@ int g2048_allgather_returns(const g2048_engine *ce, g2048_comm *c, int32_t *out,
     G2048_NCCL(g_rccl.AllGather(send, out, e->n, ncclInt32, c->comm, s));
     return G2048_OK;
 }
+
+int g2048_allgather_summary(const g2048_engine *e, g2048_comm *c, g2048_stats *out, void *stream)
+{
+    static_assert(sizeof(g2048_stats) % 8 == 0, "g2048_stats is shipped as uint64 words");
+    if (int rc = usable(e))
+        return rc;
+    if (!c || !out)
+        return fail(G2048_ERR_INVALID, "NULL argument");
+    if (c->device != e->device)
+        return fail(G2048_ERR_INVALID, "communicator is on device %d, engine on device %d", c->device, e->device);
+    if (!is_device_ptr(out))
+        return fail(G2048_ERR_INVALID, "g2048_allgather_summary needs a DEVICE buffer of `world` g2048_stats");
+    G2048_HIP(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // this rank's summary goes straight into ITS row of the gathered array (one launch), then ONE in-place all-gather of
+    // sizeof(g2048_stats) bytes per rank on the same stream: no send buffer, no stream hop, nothing for the host to wait for
+    g2048_stats *mine = out + c->rank;
+    G2048_HIP(g2048::launch_stats(tracked_state(e), static_cast<uint32_t>(e->n), e->stats_partials, e->summary_scratch,
+                                  reinterpret_cast<g2048::StatsOut *>(mine), true, s));
+    G2048_NCCL(g_rccl.AllGather(mine, out, sizeof(g2048_stats) / 8, ncclUint64, c->comm, s));
+    return G2048_OK;
+}
+
+int g2048_comm_world(const g2048_comm *c) { return c ? c->world : 0; }
+int g2048_comm_rank(const g2048_comm *c) { return c ? c->rank : -1; }
 
 int g2048_comm_local_create(const int *devices, int n_devices, g2048_comm_local **out)
 {

@@ -46,6 +46,8 @@ struct StepArgs {
     uint4 *boards_out;  // [n][16] plain cells of the board AFTER the step (and its auto-reset), or NULL
     unsigned long long *done_seq; // host-visible completion word (mapped pinned memory) or NULL: a launch of ONE block writes
     unsigned long long done_value; //   done_value there after all of its outputs (system-scope release); see g2048_step_host
+    unsigned long long *action_err; // strict actions (g2048_set_strict_actions): host-visible word that receives a report when a
+                                    //   lane reads an action outside 0..3 (game2048_env.py:49 Discrete(4)); NULL = not checked
     void *obs;          // [n][16][4][4] one-hot observation of the board AFTER the step (and its auto-reset), or NULL
     uint32_t obs_dtype; // G2048_OBS_*
     uint32_t n;
@@ -103,8 +105,12 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
 // partials: kStatsPartialWords uint64 of device scratch (stage 1 -> stage 2; field-major, one column per block)
 constexpr uint32_t kStatsBlocks = 2048;
 constexpr uint32_t kStatsPartialWords = (7 + 32) * kStatsBlocks;
-hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, bool returns_only,
-                        hipStream_t s);
+// summary_scratch: kSummaryScratchWords uint64, ZERO when first used (the one-launch returns summary keeps its block / group
+// partials and its "last one out" counters there and leaves the counters at zero)
+constexpr uint32_t kSummaryBlocks = 256;
+constexpr uint32_t kSummaryScratchWords = 2048;
+hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, unsigned long long *summary_scratch,
+                        StatsOut *dev_out, bool returns_only, hipStream_t s);
 // record <-> plain views (cells uint8[n][16], scores int32[n]); device pointers
 hipError_t launch_export_boards(const uint4 *records, uint32_t n, uint4 *cells_out, hipStream_t s);
 hipError_t launch_import_boards(uint4 *records, uint32_t n, const uint4 *cells_in, hipStream_t s);

@@ -20,6 +20,7 @@
 #include "g2048_pcg64.h"
 
 #include <atomic>
+#include <type_traits>
 
 
 namespace g2048 {
@@ -136,6 +137,41 @@ __device__ __forceinline__ uint32_t load_action(const void *actions, uint32_t i,
         return static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(actions) + i)) & 3u;
     else
         return static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const long long *>(actions) + i)) & 3u;
+}
+
+// Strict actions (g2048_set_strict_actions; game2048_env.py:49 declares Discrete(4), :210-212 happens to play 4 as "down" and
+// -1 as "right"): the same load, and whether the RAW value lies outside 0..3.  The move always uses the low two bits.
+template <int ACT>
+__device__ __forceinline__ uint32_t load_action_checked(const void *actions, uint32_t i, bool &bad, uint32_t &raw_low)
+{
+    if constexpr (ACT == 1) {
+        const uint32_t v = __builtin_nontemporal_load(static_cast<const uint8_t *>(actions) + i);
+        bad = v > 3u;
+        raw_low = v;
+        return v & 3u;
+    } else if constexpr (ACT == 2) {
+        const uint32_t v = static_cast<uint32_t>(__builtin_nontemporal_load(static_cast<const int32_t *>(actions) + i));
+        bad = v > 3u;
+        raw_low = v;
+        return v & 3u;
+    } else {
+        const unsigned long long v = static_cast<unsigned long long>(__builtin_nontemporal_load(static_cast<const long long *>(actions) + i));
+        bad = v > 3ull;
+        raw_low = static_cast<uint32_t>(v);
+        return static_cast<uint32_t>(v) & 3u;
+    }
+}
+
+// One lane of the wavefront (the first offender) publishes {bit 63, low byte of the action, global board index} to the
+// engine's pinned error word; the host finds it at the entry of its next call on the engine.  Whole wavefronts call this.
+__device__ __forceinline__ void report_bad_action(unsigned long long *action_err, bool bad, uint32_t raw_low, uint32_t global_index)
+{
+    const unsigned long long offenders = __builtin_amdgcn_ballot_w64(bad);
+    if (offenders == 0ull)
+        return;
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(offenders)))
+        __hip_atomic_store(action_err, (1ull << 63) | (static_cast<unsigned long long>(raw_low & 0xffu) << 32) | global_index,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Episode bookkeeping, shared by every step kernel.  A lane whose episode ended stores the record it
@@ -461,6 +497,7 @@ struct StepTail {
     uint4 *boards_out;  // !STD kernels only
     unsigned long long *done_seq;
     unsigned long long done_value;
+    unsigned long long *action_err; // !STD kernels only: strict actions (NULL = not checked)
 };
 
 // STD: the standard configuration -- reward and terminated present, no illegal / highest / terminal_boards, no
@@ -502,7 +539,12 @@ __device__ __forceinline__ void step_body(WaveTables *s_tables, uint4 *s_recs, u
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
 
     const Words w = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi);
-    const uint32_t action = load_action<ACT>(p.actions, i, w.w[3]);
+    uint32_t action, raw_action = 0;
+    bool bad_action = false;
+    if constexpr (!STD && ACT != 0)
+        action = load_action_checked<ACT>(p.actions, i, bad_action, raw_action);
+    else
+        action = load_action<ACT>(p.actions, i, w.w[3]);
     const LdsTables tb = stage_tables(s_tables, use_after(tables_piece, w.w[0]));
 
     const StepOut o = play_record(rec, action, w, STD ? 0u : p.max_exp, tb);
@@ -533,6 +575,10 @@ __device__ __forceinline__ void step_body(WaveTables *s_tables, uint4 *s_recs, u
             store_board(tail.boards_out, i, record_cells(rec));
     }
     flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending);
+    if constexpr (!STD && ACT != 0) {
+        if (tail.action_err) // (wave-uniform)
+            report_bad_action(tail.action_err, bad_action && valid, raw_action, p.board_offset + i);
+    }
     if constexpr (HAS_OBS)
         emit_onehot<FULL>(s_recs + (threadIdx.x & ~63u), rec, tail.obs, tail.obs_dtype, i_raw & ~63u, n);
     if (!STD && tail.done_seq)
@@ -670,6 +716,8 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
     uint32_t gained32 = 0;
     unsigned long long ended_last = 0; // lanes whose episode the LAST step ended (pending marks when auto_reset == 0)
     // step j with its action; t advances with it
+    bool bad_action = false;   // strict actions: any of this lane's k actions outside 0..3 (checked where they are fetched)
+    uint32_t bad_raw = 0;
     auto one_step = [&](uint32_t j, uint32_t action_in) {
         const size_t o_idx = static_cast<size_t>(j) * stride + i;
         const Words w = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u,
@@ -695,6 +743,17 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
     // past the end the last step's action is fetched again and never used (an unconditional load: a conditional one
     // would be waited for where the branches join)
     auto fetch = [&](uint32_t j) { return load_action_at<ACT>(actions, static_cast<size_t>(j < k ? j : k - 1u) * stride + i); };
+    // (every action that is played passes through `check` right before its step)
+    auto check = [&](typename RawAction<ACT>::type raw) {
+        if constexpr (ACT != 0) {
+            typedef typename std::make_unsigned<typename RawAction<ACT>::type>::type U;
+            if (static_cast<U>(raw) > static_cast<U>(3)) {
+                bad_action = true;
+                bad_raw = static_cast<uint32_t>(raw);
+            }
+        }
+        return static_cast<uint32_t>(raw);
+    };
     typename RawAction<ACT>::type set_b[kPrefetch];
     uint32_t j0 = 0;
     for (; j0 + 2u * kPrefetch <= k; j0 += 2u * kPrefetch) { // whole double groups
@@ -702,13 +761,13 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
         for (uint32_t q = 0; q < kPrefetch; ++q) {
             if constexpr (ACT != 0)
                 set_b[q] = fetch(j0 + q + kPrefetch);
-            one_step(j0 + q, static_cast<uint32_t>(ahead[q]));
+            one_step(j0 + q, check(ahead[q]));
         }
 #pragma unroll
         for (uint32_t q = 0; q < kPrefetch; ++q) {
             if constexpr (ACT != 0)
                 ahead[q] = fetch(j0 + q + 2u * kPrefetch);
-            one_step(j0 + kPrefetch + q, static_cast<uint32_t>(set_b[q]));
+            one_step(j0 + kPrefetch + q, check(set_b[q]));
         }
         gained += gained32;
         gained32 = 0;
@@ -717,14 +776,18 @@ __global__ void __launch_bounds__(kBlock) rollout_fused_kernel(const StepArgs p,
 #pragma unroll
     for (uint32_t q = 0; q < kPrefetch; ++q)
         if (j0 + q < k)
-            one_step(j0 + q, static_cast<uint32_t>(ahead[q]));
+            one_step(j0 + q, check(ahead[q]));
     for (uint32_t j = j0 + kPrefetch; j < k; ++j)
-        one_step(j, static_cast<uint32_t>(fetch(j)));
+        one_step(j, check(fetch(j)));
     gained += gained32; // (at most 2 * kPrefetch - 1 tail steps)
     if (valid)
         store_board_nt(p.st.boards, i, rec);
     flush_episode_counts(counters, episodes, illegal_ends, wave_sum64_lane63(valid ? gained : 0ull),
                          pending_after_step(ended_last, p.auto_reset));
+    if constexpr (ACT != 0) {
+        if (p.action_err)
+            report_bad_action(p.action_err, bad_action && valid, bad_raw, p.board_offset + i);
+    }
 }
 
 // ------------------------------------------------------------------------- numpy-RNG mode
@@ -761,8 +824,13 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
     uint32_t action;
     if constexpr (ACT == 0)
         action = philox4x32_10(p.t_lo, p.t_hi, p.board_offset + i, 0u, p.seed_lo, p.seed_hi).w[3] >> 30;
-    else
-        action = load_action<ACT>(p.actions, i, 0u);
+    else {
+        bool bad_action = false;
+        uint32_t raw_action = 0;
+        action = load_action_checked<ACT>(p.actions, i, bad_action, raw_action);
+        if (p.action_err) // strict actions (wave-uniform)
+            report_bad_action(p.action_err, bad_action && valid, raw_action, p.board_offset + i);
+    }
 
     const int32_t score_before = score;
     StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, false);
@@ -1376,6 +1444,135 @@ __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long
     }
 }
 
+// ------------------------------------------------------------- the returns summary in ONE launch
+// What the once-per-rollout exchange of a multi-GPU job ships (first option): episodes, illegal_ends and the
+// exact return_sum, from the episode slots and the live records -- the returns-only flavour of the reduction above, which
+// as a kernel PAIR cost 11-13 us at 2^20 boards behind the last step of a rollout (two launches, a 2 048-column partials
+// buffer in between).  Here: at most kSummaryBlocks blocks of 1 024 lanes (one per CU, sixteen wavefronts each), every
+// wavefront walks whole 64-board groups = whole slots (slot through the scalar cache, the pending mask with it; four
+// record loads in flight per lane), the block's three sums go to its own 32-byte partial, and the merge happens in the
+// SAME launch by "last one out": a block that finds itself the last of its group of kSummaryGroup (one device-scope
+// counter per group, each on its own cache line -- a single hot line serialises at ~88 atomics/us on this chip, so no
+// counter ever sees more than kSummaryGroup increments) adds the group's partials up, and the last group to finish adds
+// the group sums and writes *out.  The counters are left at zero for the next launch (calls on one engine are
+// stream-ordered).  Release / acquire at agent scope around the counters: the partials of a block on another XCD sit
+// behind that XCD's L2.
+constexpr uint32_t kSummaryThreads = 1024, kSummaryGroup = 16;
+constexpr uint32_t kSummaryGroups = kSummaryBlocks / kSummaryGroup;
+constexpr uint32_t kSumGroupBase = kSummaryBlocks * 4;                 // uint64 words: block partials, then group sums,
+constexpr uint32_t kSumCounterBase = kSumGroupBase + kSummaryGroups * 4; // then the counters (one 64-byte line each)
+static_assert(kSumCounterBase + (kSummaryGroups + 1) * 8 <= kSummaryScratchWords, "summary scratch size");
+static_assert(kSummaryBlocks % kSummaryGroup == 0, "whole groups");
+
+__device__ __forceinline__ unsigned long long load_agent(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_agent(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(kSummaryThreads) returns_summary_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
+                                                                          unsigned long long *scratch, StatsOut *out)
+{
+    constexpr uint32_t kWaves = kSummaryThreads / 64u, kUnroll = 4u;
+    __shared__ unsigned long long s_part[kWaves][3];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wave_stride = gridDim.x * kWaves;
+    unsigned long long episodes = 0, illegal = 0, gain = 0; // wave-uniform: the slots' counters
+    unsigned long long live = 0;                            // this lane's share of the scores of the RUNNING episodes
+    for (uint32_t w0 = blockIdx.x * kWaves + wave_in_block; w0 < n_waves; w0 += kUnroll * wave_stride) {
+        Board rec[kUnroll];
+        bool counts[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const uint32_t w = w0 + u * wave_stride;
+            const bool have = w < n_waves;                  // uniform
+            const uint32_t wc = have ? w : w0;
+            const uint32_t *slot = slot_of(st.ep_counters, wc);
+            const uint4 lo = *reinterpret_cast<const uint4 *>(slot), hi = *reinterpret_cast<const uint4 *>(slot + 4);
+            if (have) {
+                episodes += static_cast<unsigned long long>(hi.x) << 32 | lo.x;
+                illegal += static_cast<unsigned long long>(hi.y) << 32 | lo.y;
+                gain += static_cast<unsigned long long>(hi.z) << 32 | lo.z;
+            }
+            // a board whose episode has ended but which was not reset (auto_reset == 0) holds a FINISHED episode's score
+            const unsigned long long pending = static_cast<unsigned long long>(hi.w) << 32 | lo.w;
+            const uint64_t i = static_cast<uint64_t>(wc) * 64u + lane;
+            counts[u] = have && i < n && ((pending >> lane) & 1ull) == 0ull;
+            rec[u] = load_board_nt(st.boards, static_cast<uint32_t>(i < n ? i : n - 1u));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u)
+            live += counts[u] ? record_score(rec[u]) : 0u;
+    }
+    const unsigned long long live_wave = wave_sum64_lane63(live); // (every lane is here: the loop bounds are uniform)
+    if (lane == 63u) {
+        s_part[wave_in_block][0] = episodes;
+        s_part[wave_in_block][1] = illegal;
+        s_part[wave_in_block][2] = gain - live_wave;            // mod 2^64
+    }
+    __syncthreads();
+    if (tid != 0u)
+        return;
+    unsigned long long ep = 0, ill = 0, ret = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        ep += s_part[w][0];
+        ill += s_part[w][1];
+        ret += s_part[w][2];
+    }
+    const uint32_t blocks = gridDim.x, group = blockIdx.x / kSummaryGroup, groups = (blocks + kSummaryGroup - 1u) / kSummaryGroup;
+    const uint32_t first = group * kSummaryGroup, members = min(kSummaryGroup, blocks - first);
+    unsigned long long *mine = scratch + 4u * blockIdx.x;
+    store_agent(mine + 0, ep);
+    store_agent(mine + 1, ill);
+    store_agent(mine + 2, ret);
+    __threadfence(); // release: the partial before the count
+    unsigned int *group_count = reinterpret_cast<unsigned int *>(scratch + kSumCounterBase + 8u * group);
+    if (atomicAdd(group_count, 1u) != members - 1u)
+        return;
+    __threadfence(); // acquire: the count before the others' partials
+    ep = ill = ret = 0;
+    for (uint32_t b = first; b < first + members; ++b) {
+        ep += load_agent(scratch + 4u * b + 0);
+        ill += load_agent(scratch + 4u * b + 1);
+        ret += load_agent(scratch + 4u * b + 2);
+    }
+    __hip_atomic_store(group_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *gsum = scratch + kSumGroupBase + 4u * group;
+    store_agent(gsum + 0, ep);
+    store_agent(gsum + 1, ill);
+    store_agent(gsum + 2, ret);
+    __threadfence();
+    unsigned int *top_count = reinterpret_cast<unsigned int *>(scratch + kSumCounterBase + 8u * kSummaryGroups);
+    if (atomicAdd(top_count, 1u) != groups - 1u)
+        return;
+    __threadfence();
+    ep = ill = ret = 0;
+    for (uint32_t g = 0; g < groups; ++g) {
+        ep += load_agent(scratch + kSumGroupBase + 4u * g + 0);
+        ill += load_agent(scratch + kSumGroupBase + 4u * g + 1);
+        ret += load_agent(scratch + kSumGroupBase + 4u * g + 2);
+    }
+    __hip_atomic_store(top_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the terminal records were not read and nothing was counted for the histogram: "not computed" (last_score_max = -1,
+    // which no score can be), so that a reader of the struct cannot mistake the zeros for a measured mean of 0
+    out->episodes = ep;
+    out->illegal_ends = ill;
+    out->last_count = 0;
+    out->last_score_sum = 0;
+    out->last_score_max = -1;
+    out->max_exp = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        out->highest_hist[k] = 0u;
+    out->return_sum = static_cast<long long>(ret);
+}
+
 // -------------------------------------------------------------------------------- launchers
 static inline dim3 grid_for(uint64_t items) { return dim3(static_cast<uint32_t>((items + kBlock - 1) / kBlock)); }
 
@@ -1394,7 +1591,7 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
     const dim3 g = grid_for(a.n), b(kBlock);
     const bool full = a.n % kBlock == 0;
     const StepTail tail{a.terminated, a.st.last_record, a.illegal, a.highest, a.terminal_boards, a.illegal_reward, a.max_exp,
-                        a.auto_reset, a.obs, a.obs_dtype, a.boards_out, a.done_seq, a.done_value};
+                        a.auto_reset, a.obs, a.obs_dtype, a.boards_out, a.done_seq, a.done_value, a.action_err};
 #define G2048_STEP_LAUNCH(ACT, FULL, STD, OBS)                                                                          \
     do {                                                                                                                \
         uint32_t pad = 0u;                                                                                              \
@@ -1418,7 +1615,7 @@ hipError_t launch_step(const StepArgs &a, int action_dtype, hipStream_t s)
             G2048_STEP_LAUNCH(ACT, FULL, false, false);                                                                 \
     } while (0)
     const bool standard = a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0 &&
-                          !a.boards_out && !a.done_seq;
+                          !a.boards_out && !a.done_seq && !(a.action_err && action_dtype != 0);
     switch (action_dtype * 2 + (full ? 1 : 0)) {
     case 0: G2048_STEP(0, false); break;
     case 1: G2048_STEP(0, true); break;
@@ -1503,7 +1700,7 @@ hipError_t launch_reset_numpy(const StepArgs &a, const uint8_t *mask, hipStream_
 bool rollout_graph_supported(const StepArgs &a)
 {
     return a.n != 0 && a.reward && a.terminated && !a.illegal && !a.highest && !a.terminal_boards && a.max_exp == 0 && !a.boards_out &&
-           !a.done_seq && !a.obs && !a.st.rng;
+           !a.done_seq && !a.obs && !a.st.rng && !a.action_err;
 }
 
 static void *step_graph_function(int action_dtype, bool full)
@@ -1554,7 +1751,7 @@ hipError_t build_rollout_graph(const StepArgs &first, int action_dtype, uint32_t
         const unsigned long long *t_ptr = t_dev;
         float *reward = first.reward + off;
         StepTail tail{first.terminated + off, first.st.last_record, nullptr, nullptr, nullptr, first.illegal_reward, 0u, first.auto_reset,
-                      nullptr, 0u, nullptr, nullptr, 0ull};
+                      nullptr, 0u, nullptr, nullptr, 0ull, nullptr};
         void *args[11] = {&boards, &actions, &ep, &board_offset, &seed_lo, &seed_hi, &t_ptr, &n, &jj, &reward, &tail};
         hipKernelNodeParams kp{};
         kp.func = fn;
@@ -1690,15 +1887,28 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
     return hipGetLastError();
 }
 
-hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, StatsOut *dev_out, bool returns_only,
-                        hipStream_t s)
+// measurement knob (tools/stats_probe.py): G2048_SUMMARY_TWO_STAGE=1 runs the returns-only summary as the former kernel pair
+static bool two_stage_summary()
+{
+    static const bool v = [] { const char *e = std::getenv("G2048_SUMMARY_TWO_STAGE"); return e && std::atoi(e) != 0; }();
+    return v;
+}
+
+hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, unsigned long long *summary_scratch,
+                        StatsOut *dev_out, bool returns_only, hipStream_t s)
 {
     uint32_t blocks = grid_for(n).x;
     if (blocks > kStatsBlocks)
         blocks = kStatsBlocks;
     if (blocks == 0)
         blocks = 1; // n == 0: one block writes an all-zero partial
-    if (returns_only) {
+    if (returns_only && !two_stage_summary()) {
+        // ONE launch: at most kSummaryBlocks blocks of sixteen wavefronts, merged by "last one out" (see the kernel)
+        const uint32_t n_waves = (n + 63u) / 64u;
+        uint32_t sblocks = (n_waves + kSummaryThreads / 64u - 1u) / (kSummaryThreads / 64u);
+        sblocks = sblocks == 0u ? 1u : (sblocks > kSummaryBlocks ? kSummaryBlocks : sblocks);
+        hipLaunchKernelGGL(returns_summary_kernel, dim3(sblocks), dim3(kSummaryThreads), 0, s, st, n, n_waves, summary_scratch, dev_out);
+    } else if (returns_only) {
         hipLaunchKernelGGL(stats_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
         hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsScalars), dim3(kBlock), 0, s, partials, blocks, dev_out, false);
     } else {

@@ -139,7 +139,13 @@ class Game2048Env(_env_base()):
         the step kernel reads it and writes reward / flags / highest / the 16 cell bytes back into the same block, and
         ``stack()`` of those bytes is built here on the host -- no one-hot kernel, no staging copy for a single board."""
         io = self._io
-        io["actions"][0] = int(action)
+        action = int(action)
+        if not 0 <= action <= 3:
+            # action_space is Discrete(4) (:49).  The reference does not check: `int(direction / 2)` / `direction % 2`
+            # (:210-212) happen to play 4 as "down" and -1 as "right"; the engine would play the low two bits (4 -> "up").
+            # Neither accident is worth keeping: refused, nothing is stepped.
+            raise ValueError(f"action {action} is outside the action space Discrete(4) (0 up, 1 right, 2 down, 3 left)")
+        io["actions"][0] = action
         self._eng.step_host(False)
         illegal = bool(io["illegal"][0])
         info = {"illegal_move": illegal}

@@ -85,6 +85,57 @@ def allgather_stats(local_stats: torch.Tensor) -> torch.Tensor:
     return out.reshape(dist.get_world_size(), flat.numel())
 
 
+class SummaryExchange:
+    """The once-per-rollout exchange through the LIBRARY's communicator instead of the framework's process group:
+    ``g2048_allgather_summary`` = the returns-only summary kernel writing straight into this rank's row of the gathered
+    array + ONE in-place ``ncclAllGather`` (RCCL over xGMI), both enqueued on the CURRENT stream right behind the rollout's
+    last step launch -- no hop to a communication stream and back (``all_gather_into_tensor`` records an event on the
+    launch stream, waits for it on ProcessGroupNCCL's own stream, and the launch stream then waits for that one).
+
+    The communicator is created once: rank 0's ``ncclUniqueId`` reaches the others through ``torch.distributed``
+    (any backend; ``broadcast_object_list``), then ``ncclCommInitRank`` on every rank.  Without a process group it is a
+    one-rank communicator.  ``gather()`` returns the ``uint8 [world, sizeof(g2048_stats)]`` tensor (``merge_stats`` reads
+    it after the stream has been synchronised)."""
+
+    def __init__(self, engine):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self._engine = engine
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        if rank == 0:
+            _lib.check(self._lib.g2048_comm_unique_id(ident))
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        _lib.check(self._lib.g2048_comm_create(world, rank, ident, engine.device_index, C.byref(comm)))
+        self._comm = comm
+        self.world, self.rank = world, rank
+        self._row = C.sizeof(_lib.Stats)
+        self.out = torch.zeros((world, self._row), dtype=torch.uint8, device=engine.device)
+
+    def gather(self) -> torch.Tensor:
+        from . import _lib
+        e = self._engine
+        _lib.check(self._lib.g2048_allgather_summary(e._h, self._comm, self.out.data_ptr(), e._stream()))
+        return self.out
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.g2048_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def merge_stats(rows) -> dict:
     """Global summary from the gathered per-rank structs (host side, after the stream has been synchronised)."""
     from .batched import parse_stats

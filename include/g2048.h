@@ -17,7 +17,8 @@
  *    it; results are ready when the stream reaches that point.
  *  - A board is 16 x uint8 exponents, row-major: 0 = empty, k = tile 2^k (reference: int64 tile
  *    values in a 4x4 ndarray, game2048_env.py:104).  Actions: 0 up, 1 right, 2 down, 3 left
- *    (game2048_env.py:196); only the low two bits of an action are used.
+ *    (game2048_env.py:196); only the low two bits of an action are used (g2048_set_strict_actions makes a value outside
+ *    0..3 an error).
  *  - What the engine keeps per board in HBM is one 16-byte RECORD: bits [4:0] of byte j are the exponent
  *    of cell j, and the three spare bits [7:5] of bytes 8..15 hold the 24-bit "score deficit"
  *    d = (potential - score) mod 2^24, potential = sum over tiles of (e - 1) * 2^e, so that
@@ -164,6 +165,18 @@ uint64_t g2048_num_boards(const g2048_engine *e);
 int g2048_set_illegal_move_reward(g2048_engine *e, float reward);
 int g2048_set_max_tile(g2048_engine *e, int max_exp);
 
+/* Strict actions.  The reference declares Discrete(4) (game2048_env.py:49) but never checks: `int(direction / 2)` and
+ * `direction % 2` (:210-212) happen to play 4 as "down" and -1 as "right".  This library plays the low two bits of whatever
+ * it is given (4 -> "up") -- a different accident -- unless strict actions are ON: then every g2048_step / g2048_rollout /
+ * g2048_rollout_fused / g2048_step_host launch whose action buffer (G2048_ACT_U8 / I32 / I64) holds a value outside 0..3 still
+ * plays the low two bits but reports it to a per-engine error word in pinned host memory, and the NEXT call on the engine that
+ * starts after that launch has completed returns G2048_ERR_INVALID (naming one offending board), does nothing else, and clears
+ * the report.  Costs one compare per lane, and the launches use the general step kernel instead of the reward + terminated
+ * specialisation (and no cached graph): +N us per launch at 2^20 boards; default OFF.  G2048_ACT_RANDOM is never checked.
+ * g2048_step_host reads its actions from host memory and refuses BEFORE stepping anything. */
+int g2048_set_strict_actions(g2048_engine *e, int enable);
+int g2048_get_strict_actions(const g2048_engine *e);
+
 /* Game2048Env.reset (game2048_env.py:102-111) for every board: zero board, score 0, two spawns.
  * new_transaction != 0: t += 1 first (a reset that is not the first use of the stream);
  * first_slot: slot of the first spawn (0 unless continuing a transaction that already spawned).
@@ -303,8 +316,8 @@ int g2048_get_last_scores(const g2048_engine *e, int32_t *buf, void *stream);
 /* Per-board "last finished episode" bookkeeping on / off (default: on).  On: a step that ends an episode stores the
  * board's 16-byte terminal record (one sparse store per finished episode: 0.85 us of a 10.2 us launch at 2^20 boards
  * under a random policy), which is what g2048_get_last_scores, g2048_last_records_ptr, g2048_allgather_returns and
- * the last_* members of g2048_stats read.  Off: those calls fail with G2048_ERR_INVALID (the pointer is NULL, last_* are
- * zero); episodes, illegal_ends and the exact return_sum -- everything the once-per-rollout exchange of a multi-GPU job
+ * the last_* members of g2048_stats read.  Off: those calls fail with G2048_ERR_INVALID (the pointer is NULL; last_count and
+ * last_score_sum are 0 and last_score_max is -1 = NOT COMPUTED, see g2048_stats); episodes, illegal_ends and the exact return_sum -- everything the once-per-rollout exchange of a multi-GPU job
  * needs -- do not depend on it.  Switching it on again clears the stored records (enqueued on `stream`).
  * No counterpart in the reference, whose env keeps no episode history at all (SB3's Monitor does, on the host). */
 int g2048_set_last_records(g2048_engine *e, int enable, void *stream);
@@ -323,8 +336,10 @@ int g2048_episode_stats(const g2048_engine *e, g2048_stats *out, void *stream);
 int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, void *stream);
 /* The RETURNS-ONLY form of the same call -- what the once-per-rollout exchange of a multi-GPU job needs and nothing
  * else: episodes, illegal_ends and the exact return_sum, from the episode slots and the live records.  The terminal
- * records are not read and the histogram is not counted: last_count, last_score_sum, last_score_max, max_exp and
- * highest_hist[] are written as zero.  Half the traffic and two thirds of the time of the full reduction. */
+ * records are not read and the histogram is not counted: last_score_max is written as -1 = NOT COMPUTED (no score can be
+ * negative; check it before dividing last_score_sum by last_count), last_count, last_score_sum, max_exp and highest_hist[]
+ * as zero.  ONE launch (at most 256 blocks of 1 024 lanes, merged inside the launch by "last block out"): N us at 2^20
+ * boards against 21 us for the full reduction. */
 int g2048_returns_summary_async(const g2048_engine *e, g2048_stats *device_out, void *stream);
 
 /* numpy-compatible RNG mode: every board draws from its OWN numpy PCG64 exactly as the reference does
@@ -380,6 +395,15 @@ int g2048_comm_unique_id(uint8_t id[G2048_COMM_ID_BYTES]);
 int g2048_comm_create(int world, int rank, const uint8_t id[G2048_COMM_ID_BYTES], int device, g2048_comm **out);
 int g2048_comm_destroy(g2048_comm *c);
 int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, void *stream);
+/* The once-per-rollout exchange of a multi-GPU job in ONE call (first option): the returns-only summary of
+ * this engine's shard (g2048_returns_summary_async: one launch), written straight into row `rank` of out[world] (device
+ * memory), and ONE in-place ncclAllGather of the sizeof(g2048_stats)-byte rows -- both enqueued on `stream`, behind the
+ * rollout's last step: no send buffer, no hop to a communication stream and back, no host synchronisation (a framework's
+ * process-group all-gather of the same bytes costs two event hand-overs more: 26 -> N us per rollout with a one-rank
+ * group on one MI355X, profiles/r06_*).  out[r] is rank r's summary once `stream` reaches that point, on every rank. */
+int g2048_allgather_summary(const g2048_engine *e, g2048_comm *c, g2048_stats *out, void *stream);
+int g2048_comm_world(const g2048_comm *c);
+int g2048_comm_rank(const g2048_comm *c);
 /* One process driving several GPUs.  g2048_comm_local_create builds the communicator set ONCE (ncclCommInitAll over
  * `devices`, distinct; hundreds of milliseconds on 8 GPUs -- not something to pay per rollout) and
  * g2048_allgather_returns_local reuses it: engines[r] must live on devices[r] and hold equal board counts; every

@@ -99,6 +99,71 @@ int main(int argc, char **argv)
         std::printf("FAIL return_sum %lld vs the oracle's %lld\n", (long long)st.return_sum, (long long)return_sum);
         return 1;
     }
+    // ---- the returns-only summary (what a multi-GPU job ships once per rollout): the same three numbers, and the last_*
+    //      members say "not computed" -- last_score_max == -1 -- so that a C caller cannot take the zeros for a mean of 0
+    {
+        g2048_stats *d_sum;
+        HIP_OK(hipMalloc(&d_sum, sizeof(g2048_stats)));
+        HIP_OK(hipMemset(d_sum, 0xee, sizeof(g2048_stats)));
+        G_OK(g2048_returns_summary_async(eng, d_sum, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        g2048_stats ro;
+        HIP_OK(hipMemcpy(&ro, d_sum, sizeof ro, hipMemcpyDeviceToHost));
+        HIP_OK(hipFree(d_sum));
+        if (ro.last_score_max != -1 || ro.last_count != 0 || ro.last_score_sum != 0) {
+            std::printf("FAIL returns-only summary: last_score_max %d (want -1 = not computed), last_count %llu, last_score_sum %lld\n",
+                        ro.last_score_max, (unsigned long long)ro.last_count, (long long)ro.last_score_sum);
+            return 1;
+        }
+        if (ro.episodes != episodes || ro.illegal_ends != illegal_ends || ro.return_sum != return_sum) {
+            std::printf("FAIL returns-only summary differs from the oracle's books\n");
+            return 1;
+        }
+        if (st.last_score_max < 0) { // the full reduction on an engine that keeps terminal records DOES compute them
+            std::printf("FAIL g2048_episode_stats left last_score_max = %d on an engine with terminal records\n", st.last_score_max);
+            return 1;
+        }
+    }
+    // ---- strict actions through the plain C path: a 4 in the buffer is played as its low two bits (0 = up) and reported by
+    //      the NEXT call, once, as G2048_ERR_INVALID; with the switch off again it is silent
+    {
+        g2048_engine *se = nullptr;
+        G_OK(g2048_create(256, 0, seed, 0, &se));
+        G_OK(g2048_set_strict_actions(se, 1));
+        G_OK(g2048_reset(se, 0, 0, nullptr, stream));
+        std::vector<uint8_t> a(256, 1);
+        a[200] = 4;
+        uint8_t *sd_actions, *sd_term;
+        float *sd_reward;
+        HIP_OK(hipMalloc(&sd_actions, 256));
+        HIP_OK(hipMalloc(&sd_term, 256));
+        HIP_OK(hipMalloc(&sd_reward, 256 * sizeof(float)));
+        std::vector<int32_t> s_scores(256);
+        HIP_OK(hipMemcpy(sd_actions, a.data(), 256, hipMemcpyHostToDevice));
+        g2048_step_io s3{};
+        s3.actions = sd_actions;
+        s3.action_dtype = G2048_ACT_U8;
+        s3.reward = sd_reward;
+        s3.terminated = sd_term;
+        G_OK(g2048_step(se, &s3, 1, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        uint64_t clk = 0;
+        const int rc = g2048_get_scores(se, s_scores.data(), stream);
+        if (rc != G2048_ERR_INVALID || !std::strstr(g2048_last_error(), "board 200")) {
+            std::printf("FAIL strict actions: rc %d, message '%s'\n", rc, g2048_last_error());
+            return 1;
+        }
+        G_OK(g2048_get_scores(se, s_scores.data(), stream)); // reported once
+        G_OK(g2048_get_clock(se, &clk));
+        if (clk != 1) {
+            std::printf("FAIL strict actions: the offending step must still have been played (clock %llu)\n", (unsigned long long)clk);
+            return 1;
+        }
+        G_OK(g2048_destroy(se));
+        HIP_OK(hipFree(sd_actions));
+        HIP_OK(hipFree(sd_term));
+        HIP_OK(hipFree(sd_reward));
+    }
     // ---- phase 2: the step that returns its observation (g2048_step_io.obs, one launch) and the host-resident step
     //      (g2048_host_io_map / g2048_step_host: no hipMemcpy, no stream synchronisation by the caller), 12 more steps
     uint8_t *d_obs;

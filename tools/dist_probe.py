@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 
 from gym2048_amd.batched import Batched2048
-from gym2048_amd.sharding import allgather_stats, allgather_returns, weak_shard
+from gym2048_amd.sharding import allgather_stats, allgather_returns, weak_shard, SummaryExchange
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -70,7 +70,12 @@ show("one-rank RCCL group: barrier | 20 launches", region(dist.barrier, nothing)
 show("one-rank RCCL group: barrier | 20 launches + summary kernels", region(dist.barrier, lambda: eng.episode_stats_device(out=stats_buf, returns_only=True)))
 show("one-rank RCCL group: barrier | 20 launches + summary kernels + all-gather(176 B)",
      region(dist.barrier, lambda: allgather_stats(eng.episode_stats_device(out=stats_buf, returns_only=True))))
+ex = SummaryExchange(eng)                  # the library's own communicator (one rank): summary launch + in-place ncclAllGather
+ex.gather()
+torch.cuda.synchronize()
+show("one-rank RCCL group: barrier | 20 launches + g2048_allgather_summary (direct, launch stream)", region(dist.barrier, ex.gather))
 show("one-rank RCCL group: barrier | 20 launches + all-gather(176 B) of a stale buffer", region(dist.barrier, lambda: allgather_stats(stats_buf)))
 show("one-rank RCCL group: barrier | 20 launches + export + all-gather(int32[B])",
      region(dist.barrier, lambda: allgather_returns(eng.last_scores(out=ret_buf), shard)))
+ex.close()
 dist.destroy_process_group()
