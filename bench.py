@@ -476,6 +476,8 @@ def main():
     for wp in wplans:                                    # the W untimed warm-up steps of the benchmarked engine
         wp.run()
     elapsed, kernel_region_ms, collective_ms, gathered, sync_after_us = timed_region()   # THE timed region: `value`
+    if gathered is not None:
+        gathered = gathered.clone()          # (the direct exchange gathers into ONE buffer, which the repeat regions below overwrite)
     timed_chains = eng.chains_used
     # sanity inside the bench: the rollout really happened (episodes finished, rewards written) -- the engine's books as
     # they stand after THE timed region (what the gathered summaries describe)

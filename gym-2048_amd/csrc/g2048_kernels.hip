@@ -1450,35 +1450,67 @@ __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long
 // as a kernel PAIR cost 11-13 us at 2^20 boards behind the last step of a rollout (two launches, a 2 048-column partials
 // buffer in between).  Here: at most kSummaryBlocks blocks of 1 024 lanes (one per CU, sixteen wavefronts each), every
 // wavefront walks whole 64-board groups = whole slots (slot through the scalar cache, the pending mask with it; four
-// record loads in flight per lane), the block's three sums go to its own 32-byte partial, and the merge happens in the
-// SAME launch by "last one out": a block that finds itself the last of its group of kSummaryGroup (one device-scope
-// counter per group, each on its own cache line -- a single hot line serialises at ~88 atomics/us on this chip, so no
-// counter ever sees more than kSummaryGroup increments) adds the group's partials up, and the last group to finish adds
-// the group sums and writes *out.  The counters are left at zero for the next launch (calls on one engine are
-// stream-ordered).  Release / acquire at agent scope around the counters: the partials of a block on another XCD sit
-// behind that XCD's L2.
+// record loads in flight per lane), and the merge happens in the SAME launch by "last one out".
+//
+// Every word that crosses a block boundary travels by a device-scope read-modify-write and nothing else: a block PUBLISHES
+// its three sums with atomic exchanges into its own 32-byte partial, waits for their return values (an RMW returns after it
+// has been performed at the point of coherence -- the partial of a block on another XCD never sits in that XCD's L2), then
+// counts itself in.  Counting is two-level -- one counter per group of kSummaryGroup blocks and one for the groups, each on
+// its own cache line -- because a single hot line serialises at ~88 atomics/us on this chip (256 arrivals on one line:
+// up to 2.9 us; 16: 0.2).  The block that finds itself last of the last group READS the partials back with RMWs as well
+// (one lane per block, all in flight together), so there is no cache write-back or invalidate on the path at all (an
+// agent-scope fence on gfx950 is a buffer_wbl2 + buffer_inv of the whole L2: the first version of this kernel, with three
+// fence pairs and one lane walking the partials, took 15.8 us at 2^20 boards against 11.6 for the kernel pair,
+// profiles/r06_a_stats_probe_*.txt).  The counters are left at zero for the next launch (calls on one engine are
+// stream-ordered).
 constexpr uint32_t kSummaryThreads = 1024, kSummaryGroup = 16;
 constexpr uint32_t kSummaryGroups = kSummaryBlocks / kSummaryGroup;
-constexpr uint32_t kSumGroupBase = kSummaryBlocks * 4;                 // uint64 words: block partials, then group sums,
-constexpr uint32_t kSumCounterBase = kSumGroupBase + kSummaryGroups * 4; // then the counters (one 64-byte line each)
+constexpr uint32_t kSumCounterBase = kSummaryBlocks * 4;   // uint64 words: the block partials, then the counters (one 64-byte line each)
 static_assert(kSumCounterBase + (kSummaryGroups + 1) * 8 <= kSummaryScratchWords, "summary scratch size");
-static_assert(kSummaryBlocks % kSummaryGroup == 0, "whole groups");
+static_assert(kSummaryBlocks % kSummaryGroup == 0 && kSummaryBlocks <= kSummaryThreads, "whole groups; one lane per partial");
 
-__device__ __forceinline__ unsigned long long load_agent(const unsigned long long *p)
+// sum over the 16 cells of (e - 1) * 2^e as three instructions per cell: an empty cell contributes (0 - 1) << 0 = -1,
+// put back by count_empty.  (g2048_device.h potential() keeps two sums: five instructions per cell.)
+__device__ __forceinline__ uint32_t potential_lean(const Board &cells)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const uint32_t e = (cells.r[i] >> (8 * l)) & 0xffu;
+            acc += (e - 1u) << (e & 31u);
+        }
+    }
+    return acc + count_empty(cells);
 }
 
-__device__ __forceinline__ void store_agent(unsigned long long *p, unsigned long long v)
+__device__ __forceinline__ uint32_t record_score_lean(const Board &raw)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (potential_lean(record_cells(raw)) - record_deficit(raw)) & kScoreMask;
 }
+
+__device__ __forceinline__ unsigned long long rmw_exchange(unsigned long long *p, unsigned long long v)
+{
+    return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a READ as a read-modify-write: `zero` is 0 in a form the compiler cannot see through (it would turn an add of a
+// literal 0 into a plain sc1 load, which an L2 is allowed to serve)
+__device__ __forceinline__ unsigned long long rmw_read(unsigned long long *p, unsigned long long zero)
+{
+    return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the value has arrived (s_waitcnt) before anything behind this point is issued
+__device__ __forceinline__ void wait_for(unsigned long long v) { asm volatile("" ::"v"(v) : "memory"); }
 
 __global__ void __launch_bounds__(kSummaryThreads) returns_summary_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
                                                                           unsigned long long *scratch, StatsOut *out)
 {
     constexpr uint32_t kWaves = kSummaryThreads / 64u, kUnroll = 4u;
     __shared__ unsigned long long s_part[kWaves][3];
+    __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wave_stride = gridDim.x * kWaves;
@@ -1507,7 +1539,7 @@ __global__ void __launch_bounds__(kSummaryThreads) returns_summary_kernel(const 
         }
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u)
-            live += counts[u] ? record_score(rec[u]) : 0u;
+            live += counts[u] ? record_score_lean(rec[u]) : 0u;
     }
     const unsigned long long live_wave = wave_sum64_lane63(live); // (every lane is here: the loop bounds are uniform)
     if (lane == 63u) {
@@ -1516,49 +1548,73 @@ __global__ void __launch_bounds__(kSummaryThreads) returns_summary_kernel(const 
         s_part[wave_in_block][2] = gain - live_wave;            // mod 2^64
     }
     __syncthreads();
-    if (tid != 0u)
-        return;
-    unsigned long long ep = 0, ill = 0, ret = 0;
+    const uint32_t blocks = gridDim.x;
+    if (tid == 0u) {
+        unsigned long long ep = 0, ill = 0, ret = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < kWaves; ++w) {
-        ep += s_part[w][0];
-        ill += s_part[w][1];
-        ret += s_part[w][2];
+        for (uint32_t w = 0; w < kWaves; ++w) {
+            ep += s_part[w][0];
+            ill += s_part[w][1];
+            ret += s_part[w][2];
+        }
+        uint32_t last = 0u;
+        if (blocks == 1u) { // nothing to merge: wave 0 below reads these back from LDS
+            s_part[0][0] = ep;
+            s_part[0][1] = ill;
+            s_part[0][2] = ret;
+            last = 2u;
+        } else {
+            unsigned long long *mine = scratch + 4u * blockIdx.x;
+            const unsigned long long r0 = rmw_exchange(mine + 0, ep), r1 = rmw_exchange(mine + 1, ill), r2 = rmw_exchange(mine + 2, ret);
+            wait_for(r0 | r1 | r2);                             // published (performed at the point of coherence) ...
+            const uint32_t group = blockIdx.x / kSummaryGroup, groups = (blocks + kSummaryGroup - 1u) / kSummaryGroup;
+            const uint32_t members = min(kSummaryGroup, blocks - group * kSummaryGroup);
+            unsigned int *group_count = reinterpret_cast<unsigned int *>(scratch + kSumCounterBase + 8u * group);
+            unsigned int *top_count = reinterpret_cast<unsigned int *>(scratch + kSumCounterBase + 8u * kSummaryGroups);
+            if (atomicAdd(group_count, 1u) == members - 1u) {   // ... before this block counts itself in
+                atomicExch(group_count, 0u);                    // (nobody else touches it again in this launch)
+                if (atomicAdd(top_count, 1u) == groups - 1u) {
+                    atomicExch(top_count, 0u);
+                    last = 1u;
+                }
+            }
+        }
+        s_last = last;
     }
-    const uint32_t blocks = gridDim.x, group = blockIdx.x / kSummaryGroup, groups = (blocks + kSummaryGroup - 1u) / kSummaryGroup;
-    const uint32_t first = group * kSummaryGroup, members = min(kSummaryGroup, blocks - first);
-    unsigned long long *mine = scratch + 4u * blockIdx.x;
-    store_agent(mine + 0, ep);
-    store_agent(mine + 1, ill);
-    store_agent(mine + 2, ret);
-    __threadfence(); // release: the partial before the count
-    unsigned int *group_count = reinterpret_cast<unsigned int *>(scratch + kSumCounterBase + 8u * group);
-    if (atomicAdd(group_count, 1u) != members - 1u)
+    __syncthreads();
+    const uint32_t last = s_last;                               // block-uniform
+    if (last == 0u || tid >= 64u)
         return;
-    __threadfence(); // acquire: the count before the others' partials
-    ep = ill = ret = 0;
-    for (uint32_t b = first; b < first + members; ++b) {
-        ep += load_agent(scratch + 4u * b + 0);
-        ill += load_agent(scratch + 4u * b + 1);
-        ret += load_agent(scratch + 4u * b + 2);
+    // the last block out: lane b of wavefront 0 ... reads partial b, b + 64, ... (all RMWs in flight together)
+    unsigned long long ep = 0, ill = 0, ret = 0;
+    if (last == 2u) {
+        if (lane == 0u) {
+            ep = s_part[0][0];
+            ill = s_part[0][1];
+            ret = s_part[0][2];
+        }
+    } else {
+        unsigned long long v[3 * (kSummaryBlocks / 64u)];
+#pragma unroll
+        for (uint32_t q = 0; q < kSummaryBlocks / 64u; ++q) {
+            const uint32_t b = q * 64u + lane;
+            unsigned long long *theirs = scratch + 4u * (b < blocks ? b : 0u);
+#pragma unroll
+            for (uint32_t f = 0; f < 3u; ++f)
+                v[3u * q + f] = b < blocks ? rmw_read(theirs + f, last >> 8) : 0ull; // (last is 1 here)
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kSummaryBlocks / 64u; ++q) {
+            ep += v[3u * q + 0];
+            ill += v[3u * q + 1];
+            ret += v[3u * q + 2];
+        }
     }
-    __hip_atomic_store(group_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long *gsum = scratch + kSumGroupBase + 4u * group;
-    store_agent(gsum + 0, ep);
-    store_agent(gsum + 1, ill);
-    store_agent(gsum + 2, ret);
-    __threadfence();
-    unsigned int *top_count = reinterpret_cast<unsigned int *>(scratch + kSumCounterBase + 8u * kSummaryGroups);
-    if (atomicAdd(top_count, 1u) != groups - 1u)
+    ep = wave_sum64_lane63(ep);
+    ill = wave_sum64_lane63(ill);
+    ret = wave_sum64_lane63(ret); // (a sum mod 2^64: a block's gain - live may be "negative")
+    if (lane != 63u)
         return;
-    __threadfence();
-    ep = ill = ret = 0;
-    for (uint32_t g = 0; g < groups; ++g) {
-        ep += load_agent(scratch + kSumGroupBase + 4u * g + 0);
-        ill += load_agent(scratch + kSumGroupBase + 4u * g + 1);
-        ret += load_agent(scratch + kSumGroupBase + 4u * g + 2);
-    }
-    __hip_atomic_store(top_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the terminal records were not read and nothing was counted for the histogram: "not computed" (last_score_max = -1,
     // which no score can be), so that a reader of the struct cannot mistake the zeros for a measured mean of 0
     out->episodes = ep;
