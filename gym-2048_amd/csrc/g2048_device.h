@@ -39,6 +39,8 @@ static inline uint32_t g2048_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 }
 static inline uint32_t g2048_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline uint32_t g2048_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+static inline uint32_t g2048_clz(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0
+static inline uint32_t g2048_ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0
 static inline uint32_t g2048_opaque(uint32_t x) { return x; }
 static inline uint32_t g2048_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
 static inline bool g2048_any(bool x) { return x; }
@@ -50,6 +52,8 @@ template <int K> static inline uint32_t g2048_pow2_byte(uint32_t x, uint32_t) { 
 G2048_DEV uint32_t g2048_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 G2048_DEV uint32_t g2048_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 G2048_DEV uint32_t g2048_popc(uint32_t x) { return (uint32_t)__popc(x); }
+G2048_DEV uint32_t g2048_clz(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0: v_ffbh_u32
+G2048_DEV uint32_t g2048_ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0: v_ffbl_b32
 // Hides a value's origin from the optimizer.  Used on lane-wide select masks: without it LLVM turns
 // "(m & a) | (~m & b)" with m = -(cond) back into v_cndmask_b32_e64 (4 issue cycles) instead of one
 // v_bitop3_b32 (2 cycles).

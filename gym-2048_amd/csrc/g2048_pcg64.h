@@ -80,27 +80,34 @@ G2048_DEV uint32_t empty_mask16(const Board &bd)
 }
 
 // game2048_env.py:166-176 with numpy's draws.  Precondition: at least one empty cell.
+//
+// :170 Generator.shuffle of the 16 positions is a Fisher-Yates pass "for i = 15 .. 1: j = random_interval(i);
+// swap(pos[i], pos[j])", random_interval being masked rejection on 32-bit draws (a rejected draw, v > i, leaves i for the
+// next draw), and numpy serves 32-bit draws as the two halves of one 64-bit output, low half first, the high half
+// buffered.  The draws a lane consumes must be exactly numpy's (the generator goes on), but the board only needs ONE
+// thing from the shuffled order: the first empty position (:171-175).  So the loop -- the part that runs in LOCKSTEP on the
+// 128-bit LCG, one LCG step and two draws per trip -- only RECORDS the accepted j of every i (15 nibbles, pushed into a
+// 64-bit register pair: two instructions), and the permutation is never materialised.  Afterwards, in straight-line code:
+//   * where the EMPTY cells end up: the 16-bit mask of indices that hold an empty cell is pushed through the 15 swaps
+//     (bit i becomes final at step i; seven instructions per step);
+//   * the lowest such index k is the first empty position of the shuffled order; which cell sits there is found by
+//     walking index k BACKWARDS through the swaps (i = 1 .. 15: if x == i: x = j_i, else if x == j_i: x = i).
+// Round 5 swapped nibbles of a packed permutation inside the loop (eight 64-bit shifts per accepted draw): ~2 700 of the
+// ~5 000 issue cycles of a spawn; this form: ~1 000 + ~700.
 G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
 {
     const uint32_t exp = ((pcg64_next64(r) >> 11) < kTwoThreshold53) ? 1u : 2u; // :168
-    uint64_t pos = 0xFEDCBA9876543210ull;                                       // :169 nibble i = position i
-    // :170 Generator.shuffle: for i = 15 .. 1: j = random_interval(i); swap(pos[i], pos[j]), random_interval
-    // being masked rejection on 32-bit draws (a rejected draw, v > i, simply leaves i for the next draw).
-    // numpy serves 32-bit draws as the two halves of one 64-bit output, low half first, the high half buffered.
-    // The loop below keeps the wavefront in LOCKSTEP on the 128-bit LCG: a lane first uses up a half that was
-    // buffered before the call, then every iteration is ONE LCG step and TWO draws, and a lane that finishes
-    // on a low half leaves the high half in the buffer -- the draws each lane consumes are exactly numpy's.
     uint32_t i = 15;
+    uint32_t j_lo = 0, j_hi = 0; // the accepted j's, pushed: after 15 of them nibble (i - 1) of j_hi:j_lo is j_i
     auto consume = [&](uint32_t draw) {
-        const uint32_t mask = i >= 8u ? 15u : (i >= 4u ? 7u : (i >= 2u ? 3u : 1u));
-        const uint32_t j = draw & mask;
+        const uint32_t j = draw & (0xffffffffu >> g2048_clz(i)); // mask = smallest 2^m - 1 >= i (random_interval)
         if (j <= i) {
-            const uint64_t d = ((pos >> (4u * i)) ^ (pos >> (4u * j))) & 15ull; // swap nibbles i and j
-            pos ^= (d << (4u * i)) | (d << (4u * j));
+            j_hi = (j_hi << 4) | (j_lo >> 28);
+            j_lo = (j_lo << 4) | j;
             --i;
         }
     };
-    if (r.buf >> 32) {
+    if (r.buf >> 32) { // a half that was buffered before the call is used up first
         consume((uint32_t)r.buf);
         r.buf = 0;
     }
@@ -110,15 +117,26 @@ G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
         if (i >= 1u)
             consume((uint32_t)(next >> 32));
         else
-            r.buf = (next >> 32) | (1ull << 32);
+            r.buf = (next >> 32) | (1ull << 32); // a lane that finishes on a low half leaves the high half buffered
     }
-    const uint32_t empty = empty_mask16(bd);
-    uint32_t p = 0;
-    for (uint32_t k = 0; k < 16; ++k) {                                         // :171-175 first empty
-        p = (uint32_t)(pos >> (4u * k)) & 15u;
-        if ((empty >> p) & 1u)
-            break;
+    // indices holding an empty cell, pushed through the swaps: step i moves the element at j_i to index i (final from
+    // then on) and the one at i to j_i
+    uint32_t at = empty_mask16(bd), fin = 0; // pos starts as the identity: index p holds cell p
+#pragma unroll
+    for (uint32_t s = 15; s >= 1u; --s) {
+        const uint32_t j = ((s > 8u ? j_hi : j_lo) >> (4u * ((s - 1u) & 7u))) & 15u;
+        const uint32_t a = (at >> s) & 1u, b = (at >> j) & 1u;
+        fin |= b << s;
+        at = (at & ~(1u << j)) | (a << j);
     }
+    fin |= at & 1u;
+    uint32_t x = g2048_ctz(fin); // the first empty position of the shuffled order (:171-175) ...
+#pragma unroll
+    for (uint32_t s = 1; s <= 15u; ++s) { // ... and the cell that the shuffle put there
+        const uint32_t j = ((s > 8u ? j_hi : j_lo) >> (4u * ((s - 1u) & 7u))) & 15u;
+        x = x == s ? j : (x == j ? s : x);
+    }
+    const uint32_t p = x;
     const uint32_t tile = exp << (8u * (p & 3u));
     const uint32_t q = p >> 2;
     bd.r[0] |= q == 0u ? tile : 0u;

@@ -274,11 +274,18 @@ def test_bench_forced_dist_runs_the_rccl_path(torch_cuda, gather):
     assert t["launch_train_us"] > 0 and t["collective_us"] > 0
     print(f"forced-dist ({gather}): launch train {t['launch_train_us']:.1f} us, collective {t['collective_us']:.1f} us, "
           f"host tail {t['host_tail_us']:.1f} us, value {line['value']:.3e}")
-    # a loose regression bound (the measured figures are in DESIGN.md section 6: 25 us against a 200 us train): the
-    # once-per-rollout exchange must stay a fraction of the launches it follows -- with slack for a cold box, and over
-    # the six regions of the run, so that one host hiccup on a shared box (a 533 us exchange was seen once) is not a failure
-    assert min([t["collective_us"]] + t["k_region_repeats_collective_us"]) < 2 * t["launch_train_us"], t
+    # the regression bound over the SIX regions of the run, each exchange against ITS OWN launch train: one host hiccup on
+    # a shared box (a 533 us exchange was seen once, the host reached it late) is not a failure, two are -- the
+    # second-largest ratio must stay below a quarter (measured: 11-12 us behind a 195-200 us train for the summary,
+    # ~20 us for --gather full; profiles/r06_*forced_dist*.txt)
+    regions = sorted(zip([t["collective_us"]] + t["k_region_repeats_collective_us"],
+                         [t["launch_train_us"]] + t["k_region_repeats_launch_train_us"]), key=lambda r: r[0] / r[1])
+    assert len(regions) == 6 and regions[-2][0] < 0.25 * regions[-2][1], regions
     if gather == "summary":
+        # one summary launch + one in-place ncclAllGather on the launch stream (round 5: a kernel pair + the process
+        # group's all-gather with its stream hops, 26 us): the MEDIAN region stays within 14 us
+        assert cfg["collective_path"].startswith("g2048_allgather_summary"), cfg
+        assert sorted(r[0] for r in regions)[3] <= 14.0, regions
         assert line["global_returns"]["episodes"] == line["episodes_finished"]
         assert line["global_returns"]["return_sum"] == line["return_sum"] > 0
         assert line["global_returns"]["mean_episode_score"] == line["mean_episode_score"]
