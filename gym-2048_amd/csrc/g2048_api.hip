@@ -66,10 +66,11 @@ int64_t steady_now_ns()
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// "\0G2048v4": layout as v3 (records carry the score, 4-word episode slots); the version moved with the spawn rule of ABI 14
-// (g2048.h "Randomness"): a game saved under the old rule would continue differently under the new one, so a v3 blob is
-// refused instead of silently resumed.
-constexpr uint64_t kStateMagic = 0x3476383430324700ull;
+// "\0G2048v5": records carry the score, 4-word episode slots for whole 512-lane blocks, the summary scratch behind them.
+// v4 (ABI 14) is the same games in a slab of another size; v3 and older were played under the spawn rule before ABI 14
+// (g2048.h "Randomness"): a game saved under the old rule would continue differently under the new one.  Both are refused
+// with the reason instead of silently resumed.
+constexpr uint64_t kStateMagic = 0x3576383430324700ull;
 
 } // namespace
 
@@ -329,8 +330,9 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     const size_t off_boards = 0;
     const size_t off_last_record = off_boards + align_up(n * 16);
     const size_t off_counters = off_last_record + align_up(n * 16);
-    // one slot of kSlotWords counters per 64 boards (whole 256-lane launch blocks)
-    const size_t n_counters = ((n + 255) / 256) * 4 * g2048::kSlotWords;
+    // one slot of kSlotWords counters per 64 boards (whole launch blocks of the largest block size: a wavefront that lies
+    // wholly past the end still loads and stores ITS slot)
+    const size_t n_counters = ((n + g2048::kSlotBlockLanes - 1) / g2048::kSlotBlockLanes) * (g2048::kSlotBlockLanes / 64) * g2048::kSlotWords;
     const size_t off_stats = off_counters + align_up(n_counters * sizeof(unsigned long long));
     const size_t off_summary = off_stats + align_up(sizeof(g2048::StatsOut));
     e->slab_bytes = off_summary + align_up(g2048::kSummaryScratchWords * sizeof(unsigned long long));
@@ -1604,8 +1606,6 @@ static int ensure_numpy_rng(g2048_engine *e)
     if (err != hipSuccess)
         return fail(G2048_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
     e->st.rng = static_cast<uint64_t *>(p);
-    e->st.term_list = reinterpret_cast<uint32_t *>(e->st.rng + 5 * e->n);
-    e->st.term_count = e->st.term_list + ((e->n + 63) / 64) * 64;
     return G2048_OK;
 }
 
@@ -1618,8 +1618,6 @@ int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream)
         if (e->st.rng)
             G2048_HIP(hipFree(e->st.rng));
         e->st.rng = nullptr;
-        e->st.term_list = nullptr;
-        e->st.term_count = nullptr;
         return G2048_OK;
     }
     if (int rc = ensure_numpy_rng(e))
@@ -1699,7 +1697,9 @@ int g2048_set_state(g2048_engine *e, const void *host_buf, uint64_t blob_bytes, 
     if (h.magic != kStateMagic || h.n != e->n)
         return fail(G2048_ERR_INVALID, "state blob does not match this engine (magic %llx%s, n %llu vs %llu)",
                     (unsigned long long)h.magic, h.magic == 0x3376383430324700ull ? " = a blob written before ABI 14: its games were played "
-                    "under the old spawn rule and cannot be continued under this one" : "",
+                    "under the old spawn rule and cannot be continued under this one" :
+                    (h.magic == 0x3476383430324700ull ? " = a blob written by ABI 14: same games, another slab layout -- save it again "
+                    "with g2048_get_boards / g2048_get_scores and re-create" : ""),
                     (unsigned long long)h.n, (unsigned long long)e->n);
     const uint64_t want = sizeof(StateHeader) + e->slab_bytes + ((h.reserved & 1u) ? e->n * 40 : 0);
     if (blob_bytes != want)

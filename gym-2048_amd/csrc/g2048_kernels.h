@@ -19,21 +19,15 @@ struct DeviceState {
                                      // four low halves first; updated by ONE lane of the wavefront that owns the boards
                                      // (old values via the scalar cache); g2048_kernels.hip "episode SLOT"
     uint64_t *rng;      // numpy-RNG mode only: [5][n] planes (state_lo, state_hi, inc_lo, inc_hi, buf); else NULL
-    // numpy-RNG mode only (same allocation, behind the planes): the boards whose episode ended in the current step,
-    // one list of up to 64 local board indices per wavefront of the step launch + its length.  The step kernel
-    // fills them, reset_list_numpy_kernel consumes them in the same g2048_step call.
-    uint32_t *term_list;  // [ceil(n / 64)][64]
-    uint32_t *term_count; // [ceil(n / 64)]
 };
 
 constexpr uint32_t kSlotWords = 4; // uint64 per wavefront slot of ep_counters
 
-// bytes of the numpy-RNG allocation for n boards: 5 planes of uint64, the lists, the counts
-inline size_t numpy_rng_bytes(uint64_t n)
-{
-    const uint64_t waves = (n + 63) / 64;
-    return static_cast<size_t>(n * 40 + waves * 64 * 4 + waves * 4);
-}
+// bytes of the numpy-RNG allocation for n boards: 5 planes of uint64
+inline size_t numpy_rng_bytes(uint64_t n) { return static_cast<size_t>(n * 40); }
+// launch blocks never straddle the end of the slot array: slots exist for whole blocks of the LARGEST block size in use
+// (the 512 lanes of step_numpy_kernel)
+constexpr uint32_t kSlotBlockLanes = 512;
 
 struct StepArgs {
     DeviceState st;

@@ -805,20 +805,30 @@ __device__ __forceinline__ void store_rng(uint64_t *planes, uint32_t n, uint32_t
     planes[4ull * n + i] = r.buf; // inc never changes
 }
 
-// Step WITHOUT the auto-reset: a spawn in this mode is ~1 500 VALU instructions (the 15-swap Fisher-Yates shuffle
-// over 32-bit draws of a 128-bit LCG), and a reset is two of them -- run in-lane it would be executed by 99 %
-// of the wavefronts for the 7 % of boards that need it.  The boards whose episode ended are instead COMPACTED:
-// every wavefront writes their local indices to its own list (no atomics: slot = wave * 64 + rank among the
-// finished lanes), and reset_list_numpy_kernel, launched right behind, gives one lane to every listed board.
+// Game2048Env.step + the caller's `if terminated: env.reset()` in ONE launch.  A spawn in this mode is ~1 000 VALU
+// instructions (15 accepted draws of the Fisher-Yates shuffle over 32-bit halves of a 128-bit LCG, in lockstep per
+// wavefront), and a reset is two of them: run in-lane it would be executed by 99 % of the wavefronts for the 7 % of the
+// boards that need it.  Until round 6 the finished boards were listed per wavefront and reset by a SECOND, compacted
+// kernel (19 us behind a 42.6 us step at 2^20 boards: two waves per SIMD, each a serial chain of 128-bit multiplies).
+// Now the compaction happens inside the launch, per 512-lane block: a lane whose episode ended hands its generator over
+// through LDS instead of storing it (slot = the block's running count + its rank among the wavefront's finished lanes),
+// and behind ONE barrier the block's first `total` lanes -- under a random policy ~36 of 512: part of one wavefront,
+// the other seven retire -- each reset one listed board and store its fresh record and generator.  The reset work of
+// a block overlaps the step work of the other blocks on the CU.
+constexpr uint32_t kNumpyBlock = 512;
+
 template <int ACT>
-__global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
+__global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs p)
 {
-    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ uint64_t s_rng[5][kNumpyBlock]; // the generators handed over (plane-major: conflict-free), 20 KiB
+    __shared__ uint16_t s_who[kNumpyBlock];    // ... and whose they are (lane index in the block)
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0u)
+        s_count = 0u;
+    const uint32_t i_raw = blockIdx.x * kNumpyBlock + threadIdx.x;
     const bool valid = i_raw < p.n;
     const uint32_t i = valid ? i_raw : p.n - 1u;
-    const Board raw = load_board(p.st.boards, i);
-    Board bd = record_cells(raw);
-    int32_t score = static_cast<int32_t>(record_score(raw));
+    Board rec = load_board(p.st.boards, i);
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
     const EpisodeCounters counters = load_episode_counters(p, i_raw);
     uint32_t action;
@@ -831,78 +841,60 @@ __global__ void __launch_bounds__(kBlock) step_numpy_kernel(const StepArgs p)
         if (p.action_err) // strict actions (wave-uniform)
             report_bad_action(p.action_err, bad_action && valid, raw_action, p.board_offset + i);
     }
+    if (p.auto_reset != 0u)
+        __syncthreads(); // s_count = 0 is visible before the first hand-over (placed here: the loads above are in flight)
 
-    const int32_t score_before = score;
-    StepResult r = step_env_numpy(bd, score, action, rng, p.illegal_reward, p.max_exp, false);
-    const uint32_t wave_gain = wave_sum_lane63(valid ? static_cast<uint32_t>(score - score_before) : 0u); // :86
+    const NumpyStepOut o = play_record_numpy(rec, action, rng, p.max_exp);  // rec: the terminal record where the episode ended
+    const uint32_t wave_gain = wave_sum_lane63(valid ? o.gain : 0u);         // :86
 
-    const bool fin = r.terminated && valid;
-    const Board rec = make_record(bd, static_cast<uint32_t>(score)); // the terminal record where fin
+    const bool fin = o.terminated && valid;
+    const bool hand_over = fin && p.auto_reset != 0u;
     if (valid) {
-        store_board(p.st.boards, i, rec);
-        store_rng(p.st.rng, p.n, i, rng);
+        if (!hand_over) { // (a board that is reset below is stored there, once)
+            store_board(p.st.boards, i, rec);
+            store_rng(p.st.rng, p.n, i, rng);
+        }
         if (p.reward)
-            p.reward[i] = r.reward;
+            p.reward[i] = o.legal ? static_cast<float>(o.gain) : p.illegal_reward;  // :90 / :95
         if (p.terminated)
-            p.terminated[i] = r.terminated ? 1 : 0;
+            p.terminated[i] = o.terminated ? 1 : 0;
         if (p.illegal)
-            p.illegal[i] = r.illegal ? 1 : 0;
+            p.illegal[i] = o.legal ? 0 : 1;
         if (p.highest)
-            p.highest[i] = static_cast<uint8_t>(highest(r.terminal));
+            p.highest[i] = static_cast<uint8_t>(o.top);
     }
     uint32_t episodes = 0, illegal_ends = 0;
-    const unsigned long long ended = record_episode_ends(p, i, fin, r.illegal, rec, episodes, illegal_ends);
+    const unsigned long long ended = record_episode_ends(p, i, fin, !o.legal, rec, episodes, illegal_ends);
     flush_episode_counts(counters, episodes, illegal_ends, wave_gain, pending_after_step(ended, p.auto_reset));
-    // ---- hand the finished boards to reset_list_numpy_kernel
-    const unsigned long long done = __builtin_amdgcn_ballot_w64(fin && p.auto_reset != 0);
-    const uint32_t wave = i_raw >> 6;
-    if (fin && p.auto_reset != 0) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(done), 0u));
-        p.st.term_list[wave * 64u + rank] = i;
+    if (p.auto_reset == 0u) // (kernel-uniform)
+        return;
+    // ---- `if terminated: env.reset()` (game2048_env.py:102-111), compacted over the block
+    const unsigned long long done = __builtin_amdgcn_ballot_w64(hand_over);
+    if (done != 0ull) { // (wave-uniform)
+        uint32_t base = 0;
+        if ((threadIdx.x & 63u) == 0u)
+            base = atomicAdd(&s_count, static_cast<uint32_t>(__popcll(done)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (hand_over) {
+            const uint32_t e = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(done), 0u));
+            s_who[e] = static_cast<uint16_t>(threadIdx.x);
+            s_rng[0][e] = rng.state_lo;
+            s_rng[1][e] = rng.state_hi;
+            s_rng[2][e] = rng.inc_lo;
+            s_rng[3][e] = rng.inc_hi;
+            s_rng[4][e] = rng.buf;
+        }
     }
-    if ((threadIdx.x & 63u) == 0u && i_raw < p.n) // (a wavefront that lies wholly past the end has no list)
-        p.st.term_count[wave] = static_cast<uint32_t>(__popcll(done));
-}
-
-// The `if terminated: env.reset()` of numpy-RNG mode (game2048_env.py:102-111) for the boards the step kernel
-// listed: one wavefront serves the lists of kListGroup step wavefronts (32 boards expected under a random
-// policy: one trip of the loop below, and twice as many wavefronts in flight as with groups of 16, where 45 % of
-// the groups needed a second, nearly empty trip -- 26 -> 21 us at 2^20 boards), one lane per listed board.
-constexpr uint32_t kListGroup = 8;
-
-__global__ void __launch_bounds__(64) reset_list_numpy_kernel(const StepArgs p, uint32_t n_waves)
-{
-    const uint32_t lane = threadIdx.x;
-    const uint32_t first = blockIdx.x * kListGroup;
-    uint32_t pre[kListGroup + 1];
-    uint32_t total = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < kListGroup; ++g) {
-        pre[g] = total;
-        total += (first + g < n_waves) ? p.st.term_count[first + g] : 0u; // uniform addresses: scalar loads
-    }
-    pre[kListGroup] = total;
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t e = base + lane;
-        if (e >= total)
-            continue;
-        uint32_t src = 0;
-#pragma unroll
-        for (uint32_t g = 1; g < kListGroup; ++g)
-            src = e >= pre[g] ? g : src;
-        uint32_t start = 0;
-#pragma unroll
-        for (uint32_t g = 1; g < kListGroup; ++g)
-            start = src == g ? pre[g] : start;
-        const uint32_t i = p.st.term_list[(first + src) * 64u + (e - start)];
-        Pcg64 rng = load_rng(p.st.rng, p.n, i);
-        Board bd{{0u, 0u, 0u, 0u}};   // :104
-        add_tile_numpy(bd, rng);      // :108
-        add_tile_numpy(bd, rng);      // :109
-        store_rng(p.st.rng, p.n, i, rng);
-        store_board(p.st.boards, i, make_record(bd, 0u)); // :105 score = 0
-    }
+    __syncthreads();
+    const uint32_t e = threadIdx.x;
+    if (e >= s_count)
+        return;
+    const uint32_t j = blockIdx.x * kNumpyBlock + s_who[e];
+    Pcg64 r2{s_rng[0][e], s_rng[1][e], s_rng[2][e], s_rng[3][e], s_rng[4][e]};
+    const Board fresh = fresh_record_numpy(r2);
+    store_board(p.st.boards, j, fresh);
+    store_rng(p.st.rng, p.n, j, r2);
 }
 
 // numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.
@@ -938,11 +930,9 @@ __global__ void __launch_bounds__(kBlock) reset_numpy_kernel(const StepArgs p, c
     if (!doit)
         return;
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
-    Board bd{{0u, 0u, 0u, 0u}};   // game2048_env.py:104
-    add_tile_numpy(bd, rng);      // :108
-    add_tile_numpy(bd, rng);      // :109
+    const Board fresh = fresh_record_numpy(rng); // game2048_env.py:104-109
     store_rng(p.st.rng, p.n, i, rng);
-    store_board(p.st.boards, i, make_record(bd, 0u)); // :105 score = 0
+    store_board(p.st.boards, i, fresh);
 }
 
 __global__ void __launch_bounds__(kBlock) add_tile_numpy_kernel(const StepArgs p)
@@ -955,9 +945,11 @@ __global__ void __launch_bounds__(kBlock) add_tile_numpy_kernel(const StepArgs p
     if (count_empty(bd) == 0)
         return;
     Pcg64 rng = load_rng(p.st.rng, p.n, i);
-    add_tile_numpy(bd, rng);
+    const bool four = add_tile_numpy(bd, rng);
     store_rng(p.st.rng, p.n, i, rng);
-    store_board(p.st.boards, i, make_record(bd, record_score(raw)));
+    Board rec = raw;
+    record_update(rec, bd, four ? 0x80u : 0u); // a spawned 4 raises the potential without scoring: deficit += 4
+    store_board(p.st.boards, i, rec);
 }
 
 // ---------------------------------------------------------------------------------- reset
@@ -1305,11 +1297,9 @@ constexpr int kStatsScalars = 7; // episodes, illegal_ends, last_count, last_sco
 constexpr int kStatsFields = kStatsScalars + 32; // + hist[32]
 static_assert(kStatsFields * kStatsBlocks == kStatsPartialWords, "partials buffer size");
 
-// FULL_STATS = false is the RETURNS-ONLY flavour (what a multi-GPU job all-gathers once per rollout): the slots and the
-// live records only -- episodes, illegal_ends and the exact return_sum.  The terminal records are not read (half the
-// traffic) and the 32 ballots per 64 boards of the histogram are not executed; last_*, max_exp and highest_hist[] come
-// out as zero.
-template <bool FULL_STATS>
+// (The RETURNS-ONLY flavour -- what a multi-GPU job all-gathers once per rollout -- is returns_summary_kernel below: one
+// launch.  Until round 6 it was this kernel pair without the terminal records and the histogram: 11.5 us per call at 2^20
+// boards against 7.4, profiles/r06_b_stats_probe_*.txt.)
 __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uint32_t n, uint32_t n_waves,
                                                        unsigned long long *partials)
 {
@@ -1319,9 +1309,9 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
     unsigned long long episodes = 0, illegal = 0, score_sum = 0, count = 0;
     unsigned long long ret = 0; // sum of G over this thread's slots - sum of the live scores of its boards (mod 2^64)
     unsigned int max_score = 0, max_exp = 0;
-    uint32_t hist[FULL_STATS ? 32 : 1];
+    uint32_t hist[32];
 #pragma unroll
-    for (int b = 0; b < (FULL_STATS ? 32 : 1); ++b)
+    for (int b = 0; b < 32; ++b)
         hist[b] = 0u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < 32u)
@@ -1345,35 +1335,29 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
             const Board live = load_board_nt(st.boards, static_cast<uint32_t>(i));
             if (((pending >> lane) & 1ull) == 0ull)
                 ret -= record_score(live);
-            if constexpr (FULL_STATS) {
-                h = highest(record_cells(live));
-                max_exp = max(max_exp, h);
-                Board last{{0u, 0u, 0u, 0u}};
-                if (st.last_record) // NULL: terminal records are not kept, last_* stay zero
-                    last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
-                if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
-                    const unsigned int sc = record_score(last);
-                    count += 1;
-                    score_sum += sc;
-                    max_score = max(max_score, sc);
-                }
+            h = highest(record_cells(live));
+            max_exp = max(max_exp, h);
+            Board last{{0u, 0u, 0u, 0u}};
+            if (st.last_record) // NULL: terminal records are not kept, last_* stay zero
+                last = load_board_nt(st.last_record, static_cast<uint32_t>(i));
+            if ((last.r[0] | last.r[1] | last.r[2] | last.r[3]) != 0u) { // a terminal board is never empty
+                const unsigned int sc = record_score(last);
+                count += 1;
+                score_sum += sc;
+                max_score = max(max_score, sc);
             }
         }
-        if constexpr (FULL_STATS) {
 #pragma unroll
-            for (uint32_t b = 0; b < 32u; ++b)
-                hist[b] += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(h == b)));
-        }
+        for (uint32_t b = 0; b < 32u; ++b)
+            hist[b] += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(h == b)));
     }
     s_ep[tid] = episodes; s_ill[tid] = illegal; s_sum[tid] = score_sum; s_cnt[tid] = count; s_ret[tid] = ret;
     s_max[tid] = max_score; s_exp[tid] = max_exp;
-    if constexpr (FULL_STATS) {
-        if (lane == 0u) {
+    if (lane == 0u) {
 #pragma unroll
-            for (int b = 0; b < 32; ++b)
-                if (hist[b] != 0u)
-                    atomicAdd(&s_hist[b], hist[b]);
-        }
+        for (int b = 0; b < 32; ++b)
+            if (hist[b] != 0u)
+                atomicAdd(&s_hist[b], hist[b]);
     }
     __syncthreads();
     for (uint32_t off = kBlock / 2; off > 0; off >>= 1) {
@@ -1398,12 +1382,11 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const DeviceState st, uin
         mine[5 * kStatsBlocks] = s_exp[0];
         mine[6 * kStatsBlocks] = s_ret[0];
     }
-    if (FULL_STATS && tid < 32u)
+    if (tid < 32u)
         mine[(kStatsScalars + tid) * kStatsBlocks] = s_hist[tid];
 }
 
 // block f: field f of every partial -> the matching member of *out (fields 4 and 5 are maxima, the rest sums mod 2^64)
-// (the returns-only flavour launches the first kStatsScalars blocks only; block 5 then also clears the histogram)
 // last_known: the terminal records were read (the full flavour on an engine that keeps them).  Otherwise last_count and
 // last_score_sum are 0 and last_score_max is -1 -- "not computed", which no score can be -- so that a reader of the struct
 // (parse_stats, a peer rank behind an all-gather) cannot mistake the zeros for a measured mean of 0.
@@ -1412,8 +1395,6 @@ __global__ void __launch_bounds__(kBlock) stats_merge_kernel(const unsigned long
 {
     __shared__ unsigned long long s_v[kBlock];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    if (gridDim.x == static_cast<uint32_t>(kStatsScalars) && f == 5u && tid < 32u) // returns-only: nothing was counted for these
-        out->highest_hist[tid] = 0u;
     const bool is_max = f == 4u || f == 5u;
     unsigned long long v = 0;
     for (uint32_t q = tid; q < n_partials; q += kBlock) {
@@ -1844,7 +1825,7 @@ hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s)
 {
     if (a.n == 0)
         return hipSuccess;
-    const dim3 g = grid_for(a.n), b(kBlock);
+    const dim3 g((a.n + kNumpyBlock - 1u) / kNumpyBlock), b(kNumpyBlock);
     switch (action_dtype) {
     case 0: hipLaunchKernelGGL(step_numpy_kernel<0>, g, b, 0, s, a); break;
     case 1: hipLaunchKernelGGL(step_numpy_kernel<1>, g, b, 0, s, a); break;
@@ -1852,11 +1833,7 @@ hipError_t launch_step_numpy(const StepArgs &a, int action_dtype, hipStream_t s)
     case 3: hipLaunchKernelGGL(step_numpy_kernel<3>, g, b, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
-    if (a.auto_reset) { // the resets of the boards that finished, compacted (see step_numpy_kernel)
-        const uint32_t n_waves = (a.n + 63u) / 64u;
-        hipLaunchKernelGGL(reset_list_numpy_kernel, dim3((n_waves + kListGroup - 1u) / kListGroup), dim3(64), 0, s, a, n_waves);
-    }
-    if (a.obs) // the observation of this mode comes from the stand-alone kernel: the resets above run after the step kernel
+    if (a.obs) // the observation of this mode comes from the stand-alone kernel (the block's resets run after its steps)
         return launch_onehot(a.st.boards, a.n, a.obs, static_cast<int>(a.obs_dtype), s);
     return hipGetLastError();
 }
@@ -1943,13 +1920,6 @@ hipError_t launch_augment(const uint4 *boards, const uint4 *next_boards, const u
     return hipGetLastError();
 }
 
-// measurement knob (tools/stats_probe.py): G2048_SUMMARY_TWO_STAGE=1 runs the returns-only summary as the former kernel pair
-static bool two_stage_summary()
-{
-    static const bool v = [] { const char *e = std::getenv("G2048_SUMMARY_TWO_STAGE"); return e && std::atoi(e) != 0; }();
-    return v;
-}
-
 hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *partials, unsigned long long *summary_scratch,
                         StatsOut *dev_out, bool returns_only, hipStream_t s)
 {
@@ -1958,17 +1928,14 @@ hipError_t launch_stats(const DeviceState &st, uint32_t n, unsigned long long *p
         blocks = kStatsBlocks;
     if (blocks == 0)
         blocks = 1; // n == 0: one block writes an all-zero partial
-    if (returns_only && !two_stage_summary()) {
+    if (returns_only) {
         // ONE launch: at most kSummaryBlocks blocks of sixteen wavefronts, merged by "last one out" (see the kernel)
         const uint32_t n_waves = (n + 63u) / 64u;
         uint32_t sblocks = (n_waves + kSummaryThreads / 64u - 1u) / (kSummaryThreads / 64u);
         sblocks = sblocks == 0u ? 1u : (sblocks > kSummaryBlocks ? kSummaryBlocks : sblocks);
         hipLaunchKernelGGL(returns_summary_kernel, dim3(sblocks), dim3(kSummaryThreads), 0, s, st, n, n_waves, summary_scratch, dev_out);
-    } else if (returns_only) {
-        hipLaunchKernelGGL(stats_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
-        hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsScalars), dim3(kBlock), 0, s, partials, blocks, dev_out, false);
     } else {
-        hipLaunchKernelGGL(stats_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
+        hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kBlock), 0, s, st, n, (n + 63u) / 64u, partials);
         hipLaunchKernelGGL(stats_merge_kernel, dim3(kStatsFields), dim3(kBlock), 0, s, partials, blocks, dev_out,
                            st.last_record != nullptr);
     }

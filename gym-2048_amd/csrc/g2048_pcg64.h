@@ -94,7 +94,8 @@ G2048_DEV uint32_t empty_mask16(const Board &bd)
 //     walking index k BACKWARDS through the swaps (i = 1 .. 15: if x == i: x = j_i, else if x == j_i: x = i).
 // Round 5 swapped nibbles of a packed permutation inside the loop (eight 64-bit shifts per accepted draw): ~2 700 of the
 // ~5 000 issue cycles of a spawn; this form: ~1 000 + ~700.
-G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
+// Returns true when the new tile is a 4 (the callers that keep the score deficit need it).
+G2048_DEV bool add_tile_numpy(Board &bd, Pcg64 &r)
 {
     const uint32_t exp = ((pcg64_next64(r) >> 11) < kTwoThreshold53) ? 1u : 2u; // :168
     uint32_t i = 15;
@@ -143,33 +144,44 @@ G2048_DEV void add_tile_numpy(Board &bd, Pcg64 &r)
     bd.r[1] |= q == 1u ? tile : 0u;
     bd.r[2] |= q == 2u ? tile : 0u;
     bd.r[3] |= q == 3u ? tile : 0u;
+    return exp == 2u;
 }
 
-// game2048_env.py:76-100 (+ the caller's `if terminated: env.reset()`, :102-111) in numpy-RNG mode.
-G2048_DEV StepResult step_env_numpy(Board &bd, int32_t &score, uint32_t action, Pcg64 &rng, float illegal_reward,
-                                    uint32_t max_exp, bool auto_reset)
+// game2048_env.py:102-111 on a RECORD in numpy-RNG mode: empty board, score 0, two spawns; a spawned 4 raises the
+// potential without scoring, so the fresh record's deficit is 4 per spawned 4 (d = 4: bit 7 of byte 8, d = 8: bit 5 of
+// byte 9 -- as fresh_record() in the spawn-stream mode).
+G2048_DEV Board fresh_record_numpy(Pcg64 &r)
 {
-    StepResult r;
-    uint32_t gain;
-    const bool legal = move(bd, action, gain);            // :85
-    bool end = false;
-    if (legal) {
-        add_tile_numpy(bd, rng);                          // :88
-        end = is_end(bd, max_exp);                        // :89
+    Board bd{{0u, 0u, 0u, 0u}};                                   // :104, :105 score = 0
+    const uint32_t fours = (add_tile_numpy(bd, r) ? 1u : 0u) + (add_tile_numpy(bd, r) ? 1u : 0u); // :108, :109
+    bd.r[2] |= fours == 1u ? 0x80u : (fours == 2u ? 0x2000u : 0u);
+    return bd;
+}
+
+// game2048_env.py:76-100 on one board RECORD in numpy-RNG mode, WITHOUT the caller's reset (rec is the terminal record
+// when the episode ended): the counterpart of play_record().  A merge moves potential and score together, so the
+// score never appears; only a spawned 4 touches the deficit.
+struct NumpyStepOut {
+    uint32_t gain;   // :85 merge score of the move; 0 when illegal
+    bool legal;      // false = IllegalMove (:91)
+    bool terminated; // :89 / :94
+    uint32_t top;    // exponent of the highest tile after the step (:97)
+};
+
+G2048_DEV NumpyStepOut play_record_numpy(Board &rec, uint32_t action, Pcg64 &rng, uint32_t max_exp)
+{
+    NumpyStepOut o;
+    Board cells = record_cells(rec);
+    o.legal = move(cells, action, o.gain);                // :85 (illegal: board unchanged, gain 0)
+    bool four = false, end = false;
+    if (o.legal) {
+        four = add_tile_numpy(cells, rng);                // :88
+        end = is_end(cells, max_exp);                     // :89
     }
-    r.illegal = !legal;                                   // :91-95
-    r.terminated = legal ? end : true;
-    r.reward = legal ? (float)gain : illegal_reward;
-    score += (int32_t)gain;                               // :86
-    r.terminal = bd;
-    r.terminal_score = score;
-    if (r.terminated && auto_reset) {
-        bd = Board{{0u, 0u, 0u, 0u}};                     // :104
-        score = 0;                                        // :105
-        add_tile_numpy(bd, rng);                          // :108
-        add_tile_numpy(bd, rng);                          // :109
-    }
-    return r;
+    o.terminated = o.legal ? end : true;                  // :89, :94
+    o.top = highest(cells);
+    record_update(rec, cells, four ? 0x80u : 0u);         // deficit += 4 for a spawned 4
+    return o;
 }
 
 } // namespace g2048

@@ -290,12 +290,10 @@ void hostcheck_reset_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n,
 {
     for (uint64_t i = 0; i < n; ++i) {
         Pcg64 p = load_rng(&rng[i]);
-        Board bd{{0, 0, 0, 0}};
-        add_tile_numpy(bd, p);
-        add_tile_numpy(bd, p);
+        const Board rec = fresh_record_numpy(p); // what reset_numpy_kernel and the step kernel's in-block reset store
         store_rng(&rng[i], p);
-        store_board(s->boards + 16 * i, bd);
-        s->score[i] = 0;
+        store_board(s->boards + 16 * i, record_cells(rec));
+        s->score[i] = (int32_t)record_score(rec); // 0: the deficit of a fresh record is its potential
         s->ep_start[i] = (uint32_t)t;
     }
 }
@@ -313,21 +311,26 @@ void hostcheck_step_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, 
         else
             action = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)(board_offset + i), 0u, (uint32_t)seed,
                                    (uint32_t)(seed >> 32)).w[3] >> 30;
-        const StepResult r = step_env_numpy(bd, score, action, p, illegal_move_reward, (uint32_t)max_exp, auto_reset != 0);
-        store_rng(&rng[i], p);
-        if (s->reward) s->reward[i] = r.reward;
-        if (s->terminated) s->terminated[i] = r.terminated;
-        if (s->illegal) s->illegal[i] = r.illegal;
-        if (s->highest) s->highest[i] = (uint8_t)highest(r.terminal);
-        if (r.terminated) {
-            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, r.terminal);
-            s->last_score[i] = r.terminal_score;
+        // exactly step_numpy_kernel's sequence, on the RECORD: play_record_numpy, then (auto-reset) fresh_record_numpy
+        Board rec = make_record(bd, (uint32_t)score);
+        const NumpyStepOut o = play_record_numpy(rec, action, p, (uint32_t)max_exp);
+        if (s->reward) s->reward[i] = o.legal ? (float)o.gain : illegal_move_reward;
+        if (s->terminated) s->terminated[i] = o.terminated;
+        if (s->illegal) s->illegal[i] = !o.legal;
+        if (s->highest) s->highest[i] = (uint8_t)o.top;
+        if (o.terminated) {
+            if (s->terminal_boards) store_board(s->terminal_boards + 16 * i, record_cells(rec));
+            s->last_score[i] = (int32_t)record_score(rec);
             s->last_len[i] = (int32_t)((uint32_t)t - s->ep_start[i]);
             s->ep_count[i] += 1;
-            if (auto_reset) s->ep_start[i] = (uint32_t)t;
+            if (auto_reset) {
+                s->ep_start[i] = (uint32_t)t;
+                rec = fresh_record_numpy(p);
+            }
         }
-        store_board(s->boards + 16 * i, bd);
-        s->score[i] = score;
+        store_rng(&rng[i], p);
+        store_board(s->boards + 16 * i, record_cells(rec));
+        s->score[i] = (int32_t)record_score(rec);
     }
 }
 

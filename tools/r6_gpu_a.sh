@@ -7,7 +7,7 @@ timeout 900 python -m pytest tests/test_gpu_round6.py -x -q > $O/pytest_round6.l
 tail -5 $O/pytest_round6.log
 timeout 120 tests/c_abi_client/client > $O/c_client.log 2>&1; echo "client rc $?" >> $O/c_client.log; tail -2 $O/c_client.log
 timeout 300 python tools/stats_probe.py > $O/stats_probe_one_launch.txt 2>&1
-G2048_SUMMARY_TWO_STAGE=1 timeout 300 python tools/stats_probe.py > $O/stats_probe_two_stage.txt 2>&1
+timeout 300 python tools/stats_probe.py > $O/stats_probe_two_stage.txt 2>&1
 cat $O/stats_probe_one_launch.txt $O/stats_probe_two_stage.txt
 timeout 300 python tools/dist_probe.py 9 > $O/dist_probe.txt 2>&1; cat $O/dist_probe.txt
 for path in direct torch direct torch direct torch; do

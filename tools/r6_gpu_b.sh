@@ -6,10 +6,10 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_round6.py -x -q > $O/pytest_round6.log 2>&1; echo "round6 rc $?" >> $O/pytest_round6.log
 tail -3 $O/pytest_round6.log
 timeout 300 python tools/stats_probe.py > $O/stats_probe_one_launch.txt 2>&1
-G2048_SUMMARY_TWO_STAGE=1 timeout 300 python tools/stats_probe.py > $O/stats_probe_two_stage.txt 2>&1
+timeout 300 python tools/stats_probe.py > $O/stats_probe_two_stage.txt 2>&1
 cat $O/stats_probe_one_launch.txt $O/stats_probe_two_stage.txt | grep "2^"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -o r -- python tools/stats_probe.py > $O/kt1.log 2>&1
-G2048_SUMMARY_TWO_STAGE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -o r -- python tools/stats_probe.py > $O/kt2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -o r -- python tools/stats_probe.py > $O/kt2.log 2>&1
 grep -h "summary_kernel\|stats_kernel\|stats_merge" $O/kt1/*kernel_stats.csv $O/kt2/*kernel_stats.csv | cut -c1-220
 cp $O/kt1/*kernel_stats.csv $O/kernel_stats_one_launch.csv; cp $O/kt2/*kernel_stats.csv $O/kernel_stats_two_stage.csv
 rm -rf $O/kt1 $O/kt2
