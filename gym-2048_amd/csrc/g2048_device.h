@@ -40,6 +40,10 @@ static inline uint32_t g2048_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 static inline uint32_t g2048_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline uint32_t g2048_popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 static inline uint32_t g2048_clz(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0
+static inline uint32_t g2048_funnel_shr(uint32_t hi, uint32_t lo, uint32_t k) // low word of (hi:lo) >> k, 0 <= k <= 31
+{
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (k & 31u));
+}
 static inline uint32_t g2048_ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0
 static inline uint32_t g2048_opaque(uint32_t x) { return x; }
 static inline uint32_t g2048_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
@@ -53,6 +57,8 @@ G2048_DEV uint32_t g2048_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return _
 G2048_DEV uint32_t g2048_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 G2048_DEV uint32_t g2048_popc(uint32_t x) { return (uint32_t)__popc(x); }
 G2048_DEV uint32_t g2048_clz(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0: v_ffbh_u32
+// low word of (hi:lo) >> k, 0 <= k <= 31: v_alignbit_b32
+G2048_DEV uint32_t g2048_funnel_shr(uint32_t hi, uint32_t lo, uint32_t k) { return __builtin_amdgcn_alignbit(hi, lo, k); }
 G2048_DEV uint32_t g2048_ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0: v_ffbl_b32
 // Hides a value's origin from the optimizer.  Used on lane-wide select masks: without it LLVM turns
 // "(m & a) | (~m & b)" with m = -(cond) back into v_cndmask_b32_e64 (4 issue cycles) instead of one

@@ -34,18 +34,45 @@ struct Pcg64 {
 constexpr uint64_t kPcgMultHi = 0x2360ED051FC65DA4ull, kPcgMultLo = 0x4385DF649FCCF645ull;
 constexpr uint64_t kTwoThreshold53 = 8106479329266893ull; // 0.9 * 2^53 (0.9 as IEEE double)
 
+// One step of the 128-bit LCG and its output, as the two 32-bit halves numpy hands out (low half first).
+// state * MULT + inc (mod 2^128) by 32-bit limbs, schoolbook columns: the six products that reach below bit 96 are full
+// 32 x 32 + 64 -> 64 multiply-adds (v_mad_u64_u32), the four that only reach limb 3 are low halves (v_mul_lo_u32), and
+// every 64-bit addend is kept below 2^33 so that no multiply-add can overflow: (2^32 - 1)^2 + 2^33 - 2 < 2^64.  (Written
+// as two 64 x 64 -> 128 products the compiler spends 8 multiply-adds + 6 multiplies and four 64-bit adds on it; the LCG
+// step is two fifths of a spawn in this mode.)
+G2048_DEV void pcg64_step2x32(Pcg64 &r, uint32_t &out_lo, uint32_t &out_hi)
+{
+    constexpr uint32_t m0 = (uint32_t)kPcgMultLo, m1 = (uint32_t)(kPcgMultLo >> 32);
+    constexpr uint32_t m2 = (uint32_t)kPcgMultHi, m3 = (uint32_t)(kPcgMultHi >> 32);
+    const uint32_t s0 = (uint32_t)r.state_lo, s1 = (uint32_t)(r.state_lo >> 32);
+    const uint32_t s2 = (uint32_t)r.state_hi, s3 = (uint32_t)(r.state_hi >> 32);
+    const uint32_t c0 = (uint32_t)r.inc_lo, c1 = (uint32_t)(r.inc_lo >> 32);
+    const uint32_t c2 = (uint32_t)r.inc_hi, c3 = (uint32_t)(r.inc_hi >> 32);
+    const uint64_t t0 = (uint64_t)s0 * m0 + c0;                                   // column 0
+    const uint64_t u = (uint64_t)s0 * m1 + ((t0 >> 32) + c1);                     // column 1 (addend < 2^33)
+    const uint64_t v = (uint64_t)s1 * m0 + (uint32_t)u;
+    const uint64_t w1 = (uint64_t)s0 * m2 + ((u >> 32) + (v >> 32));              // column 2 (addend <= 2^33 - 2)
+    const uint64_t w2 = (uint64_t)s1 * m1 + ((uint64_t)(uint32_t)w1 + c2);
+    const uint64_t w3 = (uint64_t)s2 * m0 + (uint32_t)w2;
+    const uint32_t n0 = (uint32_t)t0, n1 = (uint32_t)v, n2 = (uint32_t)w3;
+    const uint32_t n3 = s0 * m3 + s1 * m2 + s2 * m1 + s3 * m0 + (uint32_t)(w1 >> 32) + (uint32_t)(w2 >> 32) +
+                        (uint32_t)(w3 >> 32) + c3;                                // column 3 (mod 2^32)
+    r.state_lo = n0 | ((uint64_t)n1 << 32);
+    r.state_hi = n2 | ((uint64_t)n3 << 32);
+    // out = rotr64(hi ^ lo, state >> 122): a rotation by >= 32 swaps the halves, the rest is two funnel shifts
+    const uint32_t rot = n3 >> 26;
+    const uint32_t xl = n0 ^ n2, xh = n1 ^ n3;
+    const uint32_t a = (rot & 32u) ? xh : xl, b = (rot & 32u) ? xl : xh;          // rotate (b:a) right by rot & 31
+    const uint32_t k = rot & 31u;
+    out_lo = g2048_funnel_shr(b, a, k);
+    out_hi = g2048_funnel_shr(a, b, k);
+}
+
 G2048_DEV uint64_t pcg64_next64(Pcg64 &r)
 {
-    // (state_hi:state_lo) * (MultHi:MultLo) + (inc_hi:inc_lo)  mod 2^128
-    const uint64_t lo = r.state_lo * kPcgMultLo;
-    uint64_t hi = g2048_mulhi64(r.state_lo, kPcgMultLo) + r.state_lo * kPcgMultHi + r.state_hi * kPcgMultLo;
-    const uint64_t new_lo = lo + r.inc_lo;
-    hi += r.inc_hi + (new_lo < lo ? 1ull : 0ull);
-    r.state_lo = new_lo;
-    r.state_hi = hi;
-    const uint64_t x = hi ^ new_lo;
-    const uint32_t rot = (uint32_t)(hi >> 58);
-    return (x >> rot) | (x << ((64u - rot) & 63u));
+    uint32_t lo, hi;
+    pcg64_step2x32(r, lo, hi);
+    return lo | ((uint64_t)hi << 32);
 }
 
 G2048_DEV uint32_t pcg64_next32(Pcg64 &r)
@@ -113,12 +140,13 @@ G2048_DEV bool add_tile_numpy(Board &bd, Pcg64 &r)
         r.buf = 0;
     }
     while (i >= 1u) {
-        const uint64_t next = pcg64_next64(r);
-        consume((uint32_t)next);
+        uint32_t lo, hi;
+        pcg64_step2x32(r, lo, hi);
+        consume(lo);
         if (i >= 1u)
-            consume((uint32_t)(next >> 32));
+            consume(hi);
         else
-            r.buf = (next >> 32) | (1ull << 32); // a lane that finishes on a low half leaves the high half buffered
+            r.buf = hi | (1ull << 32); // a lane that finishes on a low half leaves the high half buffered
     }
     // indices holding an empty cell, pushed through the swaps: step i moves the element at j_i to index i (final from
     // then on) and the one at i to j_i
