@@ -12,9 +12,14 @@ Loop per env-step (everything stays in HBM, everything on torch's current HIP st
      the step and writes the next (N,16,4,4) observation into the torch tensor (game2048_env.py:100).
 The first observation comes from ``observe_onehot`` after the reset.
 
-This is a consumer-side measurement (the policy is PyTorch-ROCm/MIOpen, out of scope of this repo);
-it reports env-steps/s of the whole loop and the fraction of the time spent in the env kernels.
-Prints one JSON line.  Not the driver's benchmark (that is bench.py).
+This is a consumer-side measurement (the policy is PyTorch-ROCm/MIOpen, out of scope of this repo): the line leads
+with what the ENV costs in that loop (`env_only`: the step-with-observation launches alone, from HIP events around them)
+and then gives the whole loop and the env's share of it.  MIOpen chooses its convolution kernels the first time it sees a
+shape (a "find" that benchmarks candidates, a naive fallback kernel of ~100 ms among them): that happens in an explicit
+policy warm-up over every chunk shape BEFORE anything is timed, and `policy_forward_ms_per_step_runs` lists every timed
+step so that a find that leaked into one would show.  `tools/gpu_profile.sh <tag> --policy` runs this file twice -- once
+to fill MIOpen's user find-db, once under `rocprofv3 --kernel-trace` -- and fails if any `naive_conv*` kernel appears in
+the second process.  Prints one JSON line.  Not the driver's benchmark (that is bench.py).
 """
 from __future__ import annotations
 
@@ -70,6 +75,15 @@ def run(boards=1 << 20, steps=20, warmup=3, chunk=1 << 17, dtype="float16") -> d
     actions = torch.empty(n, dtype=torch.int64, device=dev)
 
     eng.observe_onehot(out=obs)                    # observation of the reset; every later one comes from step()
+    # MIOpen's kernel selection for every shape the loop will use (the full chunk and, when n is not a multiple of it, the
+    # ragged last one), outside of anything that is timed or counted as a warm-up step
+    t_find = time.perf_counter()
+    with torch.no_grad():
+        for lo in sorted({0, (n - 1) // args.chunk * args.chunk}):
+            for _ in range(2):
+                policy(obs[lo:lo + args.chunk].contiguous(memory_format=torch.channels_last)).argmax(dim=1)
+    torch.cuda.synchronize()
+    find_s = time.perf_counter() - t_find
 
     def one_step(timers=None):
         t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), \
@@ -96,16 +110,24 @@ def run(boards=1 << 20, steps=20, warmup=3, chunk=1 << 17, dtype="float16") -> d
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_start
     onehot_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
-    policy_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
+    policy_runs = [t[1].elapsed_time(t[2]) for t in timers]
+    policy_ms = sum(policy_runs) / args.steps
     step_ms = sum(t[2].elapsed_time(t[3]) for t in timers) / args.steps
     stats = eng.episode_stats()
     eng.close()
+    obs_bytes = 38 + 256 * torch.empty(0, dtype=dt).element_size()      # the step's 38 B + the one-hot it writes
     return ({
         "metric": "env-steps/sec with a ppo_train.py-shaped policy in the loop (BASELINE configs[4])",
+        # first what the ENV costs in this loop: the int64-action step that writes its own fp16 / fp32 observation
+        "env_only": {"steps_per_s": n / (step_ms * 1e-3), "ms_per_step": step_ms, "launches_per_env_step": 1,
+                     "algorithmic_bytes_per_env_step": obs_bytes,
+                     "frac_of_hbm_peak": obs_bytes * n / (step_ms * 1e-3) / 8e12},
         "value": n * args.steps / wall, "unit": "env-steps/s", "boards": n, "steps": args.steps,
         "policy_dtype": args.dtype, "policy_chunk": args.chunk,
         "ms_per_step": {"policy_forward_argmax": policy_ms, "env_step_with_observation": step_ms,
                         "wall": wall * 1e3 / args.steps},
+        "policy_forward_ms_per_step_runs": policy_runs,          # every timed step: a MIOpen find in one of them would show
+        "policy_find_warmup_s": find_s,                           # kernel selection for every chunk shape, before anything timed
         "launches_per_env_step": 1,
         "env_fraction_of_loop": (onehot_ms + step_ms) / (onehot_ms + policy_ms + step_ms),
         "host_copies": 0, "episodes_finished": int(stats["episodes"]),

@@ -139,6 +139,7 @@ struct g2048_engine {
     struct GraphEntry {
         GraphKey key{};
         g2048::RolloutGraph g{};
+        hipStream_t last_stream = nullptr; // where it was last replayed (an entry is only evicted once that stream has drained)
     };
     static constexpr int kGraphSlots = 4;  // a trainer alternates between a few sets of rollout buffers at most
     GraphEntry graphs[kGraphSlots];        // the cached graphs, replaced round robin
@@ -147,6 +148,7 @@ struct g2048_engine {
     unsigned long long *graph_t_dev = nullptr;
     uint32_t graph_max_boards = 1u << 17; // batches up to this size use the form (G2048_GRAPH_MAX_BOARDS, read by g2048_create)
     int graph_enabled = 1;              // G2048_ROLLOUT_GRAPH=0 (read by g2048_create) turns the form off; a failing graph call too
+    char graph_off_reason[200] = "";    // ... and says why here (g2048_graph_status)
     uint64_t graph_replays = 0;         // rollouts served from the cached graph (g2048_get_graph_replays)
     // strict actions (g2048_set_strict_actions): 64 bytes of pinned, coherent host memory a step kernel reports an action
     // outside 0..3 to; read (and cleared) at the entry of the next call on the engine
@@ -335,7 +337,8 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     const size_t n_counters = ((n + g2048::kSlotBlockLanes - 1) / g2048::kSlotBlockLanes) * (g2048::kSlotBlockLanes / 64) * g2048::kSlotWords;
     const size_t off_stats = off_counters + align_up(n_counters * sizeof(unsigned long long));
     const size_t off_summary = off_stats + align_up(sizeof(g2048::StatsOut));
-    e->slab_bytes = off_summary + align_up(g2048::kSummaryScratchWords * sizeof(unsigned long long));
+    const size_t off_graph_t = off_summary + align_up(g2048::kSummaryScratchWords * sizeof(unsigned long long));
+    e->slab_bytes = off_graph_t + 256; // the clock word of the cached rollout graphs: here, so that building one allocates nothing
     err = hipMalloc(&e->slab, e->slab_bytes);
     if (err != hipSuccess) {
         const size_t wanted = e->slab_bytes;
@@ -365,6 +368,9 @@ int g2048_create(uint64_t n_boards, int device, uint64_t seed, uint64_t board_of
     e->st.ep_counters = reinterpret_cast<unsigned long long *>(base + off_counters);
     e->stats_dev = reinterpret_cast<g2048::StatsOut *>(base + off_stats);
     e->summary_scratch = reinterpret_cast<unsigned long long *>(base + off_summary);
+    e->graph_t_dev = reinterpret_cast<unsigned long long *>(base + off_graph_t);
+    if (!e->graph_enabled)
+        snprintf(e->graph_off_reason, sizeof e->graph_off_reason, "G2048_ROLLOUT_GRAPH=0 in the environment of g2048_create");
     *out = e;
     return G2048_OK;
 }
@@ -406,8 +412,6 @@ int g2048_destroy(g2048_engine *e)
                                           // hipFree of the slab below waits for the device anyway)
         for (auto &entry : e->graphs)
             g2048::destroy_rollout_graph(entry.g);
-        if (e->graph_t_dev)
-            (void)hipFree(e->graph_t_dev);
         if (e->chain_flags)
             (void)hipFree(e->chain_flags);
         if (e->chain_err_host)
@@ -717,6 +721,7 @@ int g2048_set_chains(g2048_engine *e, int chains)
 }
 
 uint64_t g2048_get_graph_replays(const g2048_engine *e) { return e ? e->graph_replays : 0; }
+const char *g2048_graph_status(const g2048_engine *e) { return e ? e->graph_off_reason : "engine is NULL"; }
 
 int g2048_get_chains(const g2048_engine *e) { return e ? e->chains : 0; }
 int g2048_get_chains_used(const g2048_engine *e) { return e ? e->last_rollout_chains : 0; }
@@ -741,30 +746,32 @@ static g2048_engine::GraphEntry *find_graph(g2048_engine *e, const g2048_engine:
 
 // Build the cached graph for `key` in the next slot (round robin).  A failure is not fatal: the engine keeps launching by
 // stream, and stops trying.
+// Builds (or rebuilds) a cached graph.  Nothing here is a stream operation -- no allocation, no memset, no synchronisation
+// (the clock word lives in the engine's slab) -- so it is safe while the application has a stream capture open, in any
+// capture mode.  An entry is evicted only when the stream it was last replayed on has drained (hipStreamQuery); otherwise
+// this rollout simply is not cached (returns NULL, the form stays on).
 static g2048_engine::GraphEntry *build_graph(g2048_engine *e, const g2048_engine::GraphKey &key, const g2048::StepArgs &a0,
                                              int action_dtype, uint32_t k_steps, uint64_t stride)
 {
     g2048_engine::GraphEntry *slot = &e->graphs[e->graph_next];
-    e->graph_next = (e->graph_next + 1) % g2048_engine::kGraphSlots;
-    if (slot->g.exec)
-        (void)hipDeviceSynchronize(); // evicting a graph that may still be replaying (a fifth set of buffers: rare)
-    g2048::destroy_rollout_graph(slot->g);
-    hipError_t err = hipSuccess;
-    if (!e->graph_t_dev) {
-        err = hipMalloc(reinterpret_cast<void **>(&e->graph_t_dev), 256);
-        if (err == hipSuccess)
-            err = hipMemset(e->graph_t_dev, 0, 256);
-        if (err == hipSuccess)
-            err = hipStreamSynchronize(nullptr); // (hipMemset only enqueues the fill)
+    if (slot->g.exec) { // a fifth set of buffers: rare
+        if (hipStreamQuery(slot->last_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr; // its last replay may still be running: keep it, launch this rollout kernel by kernel
+        }
     }
-    if (err == hipSuccess)
-        err = g2048::build_rollout_graph(a0, action_dtype, k_steps, stride, e->graph_t_dev, &slot->g);
+    e->graph_next = (e->graph_next + 1) % g2048_engine::kGraphSlots;
+    g2048::destroy_rollout_graph(slot->g);
+    const hipError_t err = g2048::build_rollout_graph(a0, action_dtype, k_steps, stride, e->graph_t_dev, &slot->g);
     if (err != hipSuccess) {
         (void)hipGetLastError();
         e->graph_enabled = 0;
+        snprintf(e->graph_off_reason, sizeof e->graph_off_reason, "building the graph of a %u-step rollout failed: %s", k_steps,
+                 hipGetErrorString(err));
         return nullptr;
     }
     slot->key = key;
+    slot->last_stream = nullptr;
     return slot;
 }
 
@@ -870,6 +877,7 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
             if (have) {
                 const hipError_t err = g2048::launch_rollout_graph(have->g, t0 + 1u, s);
                 if (err == hipSuccess) {
+                    have->last_stream = s;
                     ++e->graph_replays;
                     return G2048_OK;
                 }
@@ -878,6 +886,8 @@ int g2048_rollout(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, ui
                 (void)hipGetLastError();
                 g2048::destroy_rollout_graph(have->g);
                 e->graph_enabled = 0;
+                snprintf(e->graph_off_reason, sizeof e->graph_off_reason, "hipGraphLaunch of a cached %u-step rollout failed: %s",
+                         k_steps, hipGetErrorString(err));
             }
         }
     }

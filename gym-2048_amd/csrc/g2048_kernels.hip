@@ -818,10 +818,11 @@ __device__ __forceinline__ void store_rng(uint64_t *planes, uint32_t n, uint32_t
 constexpr uint32_t kNumpyBlock = 512;
 
 template <int ACT>
-__global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs p)
+__global__ void __launch_bounds__(kNumpyBlock, 8) step_numpy_kernel(const StepArgs p)
 {
     __shared__ uint64_t s_rng[5][kNumpyBlock]; // the generators handed over (plane-major: conflict-free), 20 KiB
-    __shared__ uint16_t s_who[kNumpyBlock];    // ... and whose they are (lane index in the block)
+    __shared__ uint16_t s_who[kNumpyBlock];    // ... whose they are (lane index in the block) ...
+    __shared__ uint8_t s_first[kNumpyBlock];   // ... and the first tile of the reset where it is drawn already: cell | four << 4, else 0xff
     __shared__ uint32_t s_count;
     if (threadIdx.x == 0u)
         s_count = 0u;
@@ -844,7 +845,8 @@ __global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs 
     if (p.auto_reset != 0u)
         __syncthreads(); // s_count = 0 is visible before the first hand-over (placed here: the loads above are in flight)
 
-    const NumpyStepOut o = play_record_numpy(rec, action, rng, p.max_exp);  // rec: the terminal record where the episode ended
+    // rec: the terminal record where the episode ended.  A lane whose move is illegal draws the first tile of its reset here
+    const NumpyStepOut o = play_record_numpy(rec, action, rng, p.max_exp, p.auto_reset != 0u);
     const uint32_t wave_gain = wave_sum_lane63(valid ? o.gain : 0u);         // :86
 
     const bool fin = o.terminated && valid;
@@ -879,6 +881,7 @@ __global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs 
             const uint32_t e = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(done), 0u));
             s_who[e] = static_cast<uint16_t>(threadIdx.x);
+            s_first[e] = o.have_first ? static_cast<uint8_t>(o.first_cell | (o.first_four ? 16u : 0u)) : static_cast<uint8_t>(0xffu);
             s_rng[0][e] = rng.state_lo;
             s_rng[1][e] = rng.state_hi;
             s_rng[2][e] = rng.inc_lo;
@@ -887,14 +890,19 @@ __global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs 
         }
     }
     __syncthreads();
-    const uint32_t e = threadIdx.x;
-    if (e >= s_count)
+    const uint32_t total = s_count;
+    if ((threadIdx.x & ~63u) >= total) // (whole wavefronts stay or go: finish_record_numpy votes)
         return;
+    const bool mine = threadIdx.x < total;
+    const uint32_t e = mine ? threadIdx.x : 0u;
     const uint32_t j = blockIdx.x * kNumpyBlock + s_who[e];
+    const uint32_t first = s_first[e];
     Pcg64 r2{s_rng[0][e], s_rng[1][e], s_rng[2][e], s_rng[3][e], s_rng[4][e]};
-    const Board fresh = fresh_record_numpy(r2);
-    store_board(p.st.boards, j, fresh);
-    store_rng(p.st.rng, p.n, j, r2);
+    const Board fresh = finish_record_numpy(r2, first != 0xffu || !mine, first & 15u, (first & 16u) != 0u);
+    if (mine) {
+        store_board(p.st.boards, j, fresh);
+        store_rng(p.st.rng, p.n, j, r2);
+    }
 }
 
 // numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.

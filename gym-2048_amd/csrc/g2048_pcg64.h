@@ -121,8 +121,8 @@ G2048_DEV uint32_t empty_mask16(const Board &bd)
 //     walking index k BACKWARDS through the swaps (i = 1 .. 15: if x == i: x = j_i, else if x == j_i: x = i).
 // Round 5 swapped nibbles of a packed permutation inside the loop (eight 64-bit shifts per accepted draw): ~2 700 of the
 // ~5 000 issue cycles of a spawn; this form: ~1 000 + ~700.
-// Returns true when the new tile is a 4 (the callers that keep the score deficit need it).
-G2048_DEV bool add_tile_numpy(Board &bd, Pcg64 &r)
+// Returns true when the new tile is a 4 (the callers that keep the score deficit need it); `where` = its cell.
+G2048_DEV bool add_tile_numpy(Board &bd, Pcg64 &r, uint32_t &where)
 {
     const uint32_t exp = ((pcg64_next64(r) >> 11) < kTwoThreshold53) ? 1u : 2u; // :168
     uint32_t i = 15;
@@ -172,7 +172,21 @@ G2048_DEV bool add_tile_numpy(Board &bd, Pcg64 &r)
     bd.r[1] |= q == 1u ? tile : 0u;
     bd.r[2] |= q == 2u ? tile : 0u;
     bd.r[3] |= q == 3u ? tile : 0u;
+    where = p;
     return exp == 2u;
+}
+
+G2048_DEV bool add_tile_numpy(Board &bd, Pcg64 &r)
+{
+    uint32_t where;
+    return add_tile_numpy(bd, r, where);
+}
+
+// a board holding one tile (a 2, or a 4 when `four`) in cell p
+G2048_DEV Board one_tile_board(uint32_t p, bool four)
+{
+    const uint32_t tile = (four ? 2u : 1u) << (8u * (p & 3u)), q = p >> 2;
+    return Board{{q == 0u ? tile : 0u, q == 1u ? tile : 0u, q == 2u ? tile : 0u, q == 3u ? tile : 0u}};
 }
 
 // game2048_env.py:102-111 on a RECORD in numpy-RNG mode: empty board, score 0, two spawns; a spawned 4 raises the
@@ -186,6 +200,25 @@ G2048_DEV Board fresh_record_numpy(Pcg64 &r)
     return bd;
 }
 
+// The same reset when its FIRST spawn (:108) has already been drawn -- tile in cell `first_cell`, a 4 when `first_four` --
+// for the lanes where `have_first`; the others draw both.  (The step kernel lets a lane whose move was illegal draw the
+// first tile of its reset while the rest of its wavefront draws the step's spawn: an illegal move spawns nothing, :91-95,
+// so that lane would idle, and the generator is consumed in the reference's order either way.)  Whole wavefronts call this.
+G2048_DEV Board finish_record_numpy(Pcg64 &r, bool have_first, uint32_t first_cell, bool first_four)
+{
+    Board bd = one_tile_board(first_cell, first_four);
+    uint32_t fours = first_four ? 1u : 0u;
+    if (g2048_any(!have_first)) { // (wave-uniform: under a random policy nearly every episode ends on an illegal move)
+        if (!have_first) {
+            bd = Board{{0u, 0u, 0u, 0u}};
+            fours = add_tile_numpy(bd, r) ? 1u : 0u;              // :108
+        }
+    }
+    fours += add_tile_numpy(bd, r) ? 1u : 0u;                     // :109
+    bd.r[2] |= fours == 1u ? 0x80u : (fours == 2u ? 0x2000u : 0u);
+    return bd;
+}
+
 // game2048_env.py:76-100 on one board RECORD in numpy-RNG mode, WITHOUT the caller's reset (rec is the terminal record
 // when the episode ended): the counterpart of play_record().  A merge moves potential and score together, so the
 // score never appears; only a spawned 4 touches the deficit.
@@ -194,21 +227,36 @@ struct NumpyStepOut {
     bool legal;      // false = IllegalMove (:91)
     bool terminated; // :89 / :94
     uint32_t top;    // exponent of the highest tile after the step (:97)
+    bool have_first; // early_reset only: the move was illegal and the FIRST tile of the reset that follows (:108) is drawn:
+    uint32_t first_cell; //   its cell
+    bool first_four;     //   and whether it is a 4
 };
 
-G2048_DEV NumpyStepOut play_record_numpy(Board &rec, uint32_t action, Pcg64 &rng, uint32_t max_exp)
+// early_reset (the caller resets a board whose episode ends, :102-111): a lane whose move is illegal spawns nothing in its
+// step (:91-95) and would sit out the wavefront's lockstep spawn -- it draws the first tile of its reset there instead
+// (same generator, same order: nothing else draws in between).
+G2048_DEV NumpyStepOut play_record_numpy(Board &rec, uint32_t action, Pcg64 &rng, uint32_t max_exp, bool early_reset)
 {
     NumpyStepOut o;
     Board cells = record_cells(rec);
     o.legal = move(cells, action, o.gain);                // :85 (illegal: board unchanged, gain 0)
+    o.have_first = !o.legal && early_reset;
+    o.first_cell = 0;
     bool four = false, end = false;
-    if (o.legal) {
-        four = add_tile_numpy(cells, rng);                // :88
-        end = is_end(cells, max_exp);                     // :89
+    if (o.legal || o.have_first) {
+        Board target = cells;
+        if (!o.legal)
+            target = Board{{0u, 0u, 0u, 0u}};             // :104
+        four = add_tile_numpy(target, rng, o.first_cell); // :88 / :108
+        if (o.legal) {
+            cells = target;
+            end = is_end(cells, max_exp);                 // :89
+        }
     }
+    o.first_four = four;
     o.terminated = o.legal ? end : true;                  // :89, :94
     o.top = highest(cells);
-    record_update(rec, cells, four ? 0x80u : 0u);         // deficit += 4 for a spawned 4
+    record_update(rec, cells, (o.legal && four) ? 0x80u : 0u); // deficit += 4 for a spawned 4
     return o;
 }
 

@@ -313,7 +313,7 @@ void hostcheck_step_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, 
                                    (uint32_t)(seed >> 32)).w[3] >> 30;
         // exactly step_numpy_kernel's sequence, on the RECORD: play_record_numpy, then (auto-reset) fresh_record_numpy
         Board rec = make_record(bd, (uint32_t)score);
-        const NumpyStepOut o = play_record_numpy(rec, action, p, (uint32_t)max_exp);
+        const NumpyStepOut o = play_record_numpy(rec, action, p, (uint32_t)max_exp, auto_reset != 0);
         if (s->reward) s->reward[i] = o.legal ? (float)o.gain : illegal_move_reward;
         if (s->terminated) s->terminated[i] = o.terminated;
         if (s->illegal) s->illegal[i] = !o.legal;
@@ -325,7 +325,7 @@ void hostcheck_step_batch_numpy(g2048o_batch *s, g2048o_pcg64 *rng, uint64_t n, 
             s->ep_count[i] += 1;
             if (auto_reset) {
                 s->ep_start[i] = (uint32_t)t;
-                rec = fresh_record_numpy(p);
+                rec = finish_record_numpy(p, o.have_first, o.first_cell, o.first_four);
             }
         }
         store_rng(&rng[i], p);
