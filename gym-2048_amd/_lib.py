@@ -95,6 +95,7 @@ SIGNATURES = {
     "g2048_get_chains": (C.c_int, [_E]),
     "g2048_get_chains_used": (C.c_int, [_E]),
     "g2048_get_graph_replays": (C.c_uint64, [_E]),
+    "g2048_graph_status": (C.c_char_p, [_E]),
     "g2048_rollout_fused": (C.c_int, [_E, _u32, C.POINTER(StepIO), _u64, C.c_int, _S]),
     "g2048_rollout_random": (C.c_int, [_E, _u32, _S]),
     "g2048_move": (C.c_int, [_E, C.c_void_p, _i32, C.c_int, C.c_void_p, C.c_void_p, _S]),

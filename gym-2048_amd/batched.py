@@ -198,6 +198,11 @@ class Batched2048:
         return int(self._lib.g2048_get_graph_replays(self._h))
 
     @property
+    def graph_status(self) -> str:
+        """``""`` while cached-graph replays are available to this engine, else why they are off (``g2048_graph_status``)."""
+        return self._lib.g2048_graph_status(self._h).decode(errors="replace")
+
+    @property
     def last_records_enabled(self) -> bool:
         return bool(self._lib.g2048_get_last_records(self._h))
 

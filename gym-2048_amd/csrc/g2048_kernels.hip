@@ -815,10 +815,13 @@ __device__ __forceinline__ void store_rng(uint64_t *planes, uint32_t n, uint32_t
 // and behind ONE barrier the block's first `total` lanes -- under a random policy ~36 of 512: part of one wavefront,
 // the other seven retire -- each reset one listed board and store its fresh record and generator.  The reset work of
 // a block overlaps the step work of the other blocks on the CU.
+// (512 lanes: 45.0-46.1 us per step at 2^20 boards against 48.2 / 48.7 / 48.4 for 256 / 768 / 1 024, one box,
+//  profiles/r06_d_numpy_block_ab.txt; forcing 8 waves per SIMD -- 64 VGPRs, five dwords spilled -- changes nothing)
 constexpr uint32_t kNumpyBlock = 512;
+static_assert(kNumpyBlock == kSlotBlockLanes, "the slot array is sized for whole blocks of this kernel");
 
 template <int ACT>
-__global__ void __launch_bounds__(kNumpyBlock, 8) step_numpy_kernel(const StepArgs p)
+__global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs p)
 {
     __shared__ uint64_t s_rng[5][kNumpyBlock]; // the generators handed over (plane-major: conflict-free), 20 KiB
     __shared__ uint16_t s_who[kNumpyBlock];    // ... whose they are (lane index in the block) ...

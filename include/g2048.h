@@ -250,8 +250,14 @@ int g2048_get_chains_used(const g2048_engine *e);
  * kernels, bit-identical results; nothing to configure (G2048_ROLLOUT_GRAPH=0 in the environment of g2048_create turns
  * it off).  Returns how many rollouts of this engine were served that way. */
 uint64_t g2048_get_graph_replays(const g2048_engine *e);
+/* "" while the form is available; otherwise why it is off for this engine (G2048_ROLLOUT_GRAPH=0, or the HIP call that failed:
+ * a failing graph build / launch turns the form off for the engine's lifetime and its rollouts are launched kernel by kernel). */
+const char *g2048_graph_status(const g2048_engine *e);
 /* Plan preparation: build the cached graph for exactly this rollout NOW (no step is executed, nothing is enqueued), so that
- * already the first g2048_rollout with these arguments is a replay.  A no-op where the form does not apply. */
+ * already the first g2048_rollout with these arguments is a replay.  A no-op where the form does not apply.  No stream
+ * operation is involved (no allocation, fill or synchronisation: the graph's clock word is part of the engine), so it may be
+ * called while the application has a stream capture open; a fifth set of buffers replaces the oldest cached graph only once
+ * the stream that one was last replayed on has drained (otherwise that rollout simply is not cached). */
 int g2048_rollout_prepare(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset);
 
 /* The same k steps as g2048_rollout -- same actions in, bit-identical reward / terminated / illegal /

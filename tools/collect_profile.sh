@@ -28,4 +28,13 @@ cp $S/bench_under_rocprof.json profiles/${T}_bench_under_rocprof.json
 [ -f $S/kernel_stats_extras.csv ] && cp $S/kernel_stats_extras.csv profiles/${T}_kernel_stats_extras.csv
 [ -f $S/summary_obs_kernel.txt ] && cp $S/summary_obs_kernel.txt profiles/${T}_obs_kernel_summary.txt
 [ -f $S/bench_extras_under_rocprof.json ] && cp $S/bench_extras_under_rocprof.json profiles/${T}_bench_extras_under_rocprof.json
+for L in 2p16 2p24; do    # the step kernel per batch size (round 6): kernel trace, FETCH / WRITE summary, the line under the profiler
+  [ -f $S/kernel_stats_$L.csv ] && cp $S/kernel_stats_$L.csv profiles/${T}_kernel_stats_$L.csv
+  [ -f $S/summary_$L.txt ] && cp $S/summary_$L.txt profiles/${T}_summary_$L.txt
+  [ -f $S/bench_${L}_under_rocprof.json ] && cp $S/bench_${L}_under_rocprof.json profiles/${T}_bench_${L}_under_rocprof.json
+done
+cp $S/kernel_stats.csv profiles/${T}_kernel_stats_2p20.csv    # (the main set IS the 2^20 one: same file under the per-size name)
+[ -f $S/kernel_stats_policy.csv ] && cp $S/kernel_stats_policy.csv profiles/${T}_kernel_stats_policy.csv
+[ -f $S/policy_naive_conv_check.txt ] && cp $S/policy_naive_conv_check.txt profiles/${T}_policy_naive_conv_check.txt
+[ -f $S/policy_under_rocprof.json ] && cp $S/policy_under_rocprof.json profiles/${T}_policy_under_rocprof.json
 python -c "import bench, json; t = json.load(open('profiles/traffic_latest.json')); print('profile', t['profile'], 'csrc', t['csrc_sha16'], 'current', bench.csrc_hash())"
