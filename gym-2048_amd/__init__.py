@@ -21,10 +21,23 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-def register(entry_point="gym2048_amd:Game2048Env"):
-    """Register ``'2048-v0'`` with gymnasium like the reference's ``env/__init__.py:1-6``."""
-    from gymnasium.envs.registration import register as _register
-    _register(id=ENV_ID, entry_point=entry_point)
+def register(entry_point="gym2048_amd:Game2048Env", force=True):
+    """Register ``'2048-v0'`` with gymnasium like the reference's ``env/__init__.py:1-6``.
+
+    ``force=False`` (what the import-time registration uses): when the id already points at ANOTHER entry point -- the
+    reference's own ``env`` package imported in the same process registers the same id -- that registration is KEPT and a
+    ``UserWarning`` says so (``gym.make("2048-v0")`` would otherwise silently change meaning with the import order);
+    call ``gym2048_amd.register()`` explicitly to take the id over.  Returns True when the id now points here."""
+    from gymnasium.envs import registration
+    existing = getattr(registration, "registry", {}).get(ENV_ID) if hasattr(getattr(registration, "registry", None), "get") else None
+    current = getattr(existing, "entry_point", None)
+    if existing is not None and current != entry_point and not force:
+        import warnings
+        warnings.warn(f"gym2048_amd: '{ENV_ID}' is already registered with entry point {current!r}; keeping it.  "
+                      f"Call gym2048_amd.register() to point '{ENV_ID}' at the MI355X engine instead.", UserWarning, stacklevel=2)
+        return False
+    registration.register(id=ENV_ID, entry_point=entry_point)
+    return True
 
 
 # env/__init__.py:1-6 registers '2048-v0' when the package is imported, and its callers rely on that
@@ -35,5 +48,5 @@ try:
 except ImportError:
     _gymnasium = None
 if _gymnasium is not None:
-    register()
+    register(force=False)
 del _gymnasium

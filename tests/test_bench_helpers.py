@@ -14,6 +14,19 @@ def test_cpu_baseline_shape():
     assert bench.python_port_rate() > 1e3
 
 
+def test_cpu_baseline_team_is_calibrated_and_capped_at_the_physical_cores():
+    """Round 5's CPU figure halved between two driver runs because the OpenMP team was picked from a two-step sample and
+    could be an oversubscribed one: the team is now calibrated on >= 0.3 s per candidate, capped at the physical cores, and
+    the line says what was tried and on which CPU."""
+    info = bench.host_cpu_info()
+    assert 1 <= info["physical_cores"] <= info["visible_cpus"]
+    cb = bench.cpu_baseline(0.3)
+    tried = {int(k): v for k, v in cb["threads_tried"].items()}
+    assert 1 in tried and max(tried) <= info["physical_cores"] and all(v > 1e5 for v in tried.values())
+    assert cb["cores"] == max(tried, key=tried.get) and cb["physical_cores"] == info["physical_cores"]
+    assert abs(cb["per_core_value"] - cb["value"] / cb["cores"]) < 1e-6 * cb["value"] and "cpu_model" in cb
+
+
 def test_constants_match_the_roofline_model():
     assert bench.ALGO_BYTES_PER_STEP == 16 + 1 + 16 + 4 + 1      # BASELINE.md section 4
     assert bench.HBM_PEAK_GBS == 8000.0

@@ -222,7 +222,22 @@ def test_fresh_record_through_the_one_tile_table(host_check):
     rng = np.random.default_rng(4)
     a, b = np.zeros(16, np.uint8), np.zeros(16, np.uint8)
     words = rng.integers(0, 2 ** 32, size=(20000, 2), dtype=np.uint64)
-    words[:64, 0] = (np.arange(64) % 16) << 28 | 0xFFFF * (np.arange(64) // 32)   # every cell, both tile values
+    # directed: every cell of the first tile with BOTH tile values -- under the ABI-14 spawn rule the value comes from the
+    # fraction the position leaves over, (w1 << 4) > 3865470566, so the low 28 bits are all-zero (a 2) / all-one (a 4) ...
+    cell = np.arange(64) % 16
+    words[:64, 0] = (cell << 28) | (0x0FFFFFFF * (np.arange(64) // 32))
+    assert all(((int(w) << 4) & 0xFFFFFFFF > 3865470566) == (k >= 32) for k, w in enumerate(words[:64, 0]))
+    # ... and the second tile just below / above the threshold of ITS rule, w2 * 15 mod 2^32 > 3865470566, in several cells
+    thr = 3865470566
+    for k in range(32):
+        base = (k % 15) * 2 ** 32 + thr + (1 if k >= 16 else 0)          # w2 * 15 = base (+ up to 14): k-th empty cell, value 2 / 4
+        w2 = -(-base // 15)
+        words[64 + k, 1] = w2
+        assert (w2 * 15) >> 32 == k % 15 and ((w2 * 15) & 0xFFFFFFFF > thr) == ((w2 * 15) & 0xFFFFFFFF >= thr + 1)
+    fours_seen = 0
+    for w1, w2 in words[:96]:
+        fours_seen += ((int(w1) << 4) & 0xFFFFFFFF > thr) + ((int(w2) * 15) & 0xFFFFFFFF > thr)
+    assert fours_seen >= 40                                               # the deficit bit of a spawned 4 is really exercised
     for w1, w2 in words:
         host_check.hostcheck_fresh_record_lut(int(w1), int(w2), a.ctypes.data_as(U8P), b.ctypes.data_as(U8P))
         assert np.array_equal(a, b), (hex(int(w1)), hex(int(w2)))

@@ -95,6 +95,20 @@ def test_step_reward_score_and_illegal():
     assert c.step(0)[1] == -0.1 and c.reward_range == (-0.1, 65536.0)
 
 
+def test_step_refuses_actions_outside_discrete4():
+    """action_space is Discrete(4) (game2048_env.py:49).  The reference never checks and `int(direction / 2)` /
+    `direction % 2` (:210-212) happen to play 4 as "down" and -1 as "right"; the engine would play the low two bits.
+    The drop-in refuses instead: ValueError, board, score and spawn slot untouched."""
+    b = make_env(seed=3)
+    before, score = b.get_board().copy(), b.score
+    for bad in (4, -1, 255, np.int64(7)):
+        with pytest.raises(ValueError, match=r"Discrete\(4\)"):
+            b.step(bad)
+    assert np.array_equal(b.get_board(), before) and b.score == score
+    for good in (0, np.int64(1), np.uint8(2), 3):
+        b.step(good)
+
+
 def test_observation_is_one_hot_and_matches_stack():
     b = make_env(seed=0)
     b.set_board(np.array([[2, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 4, 0]]))
@@ -403,6 +417,7 @@ def test_stats_rows_without_terminal_records_read_as_unknown_not_zero():
     summary = Stats(episodes=6, illegal_ends=0, last_count=0, last_score_sum=0, last_score_max=-1, max_exp=5, return_sum=300)
     a, b = parse_stats(bytes(full)), parse_stats(bytes(summary))
     assert (a["last_count"], a["last_score_sum"], a["last_score_max"], a["mean_last_score"]) == (4, 400, 150, 100.0)
+    assert a["last_known"] is True and b["last_known"] is False      # the explicit flag next to the None values
     assert b["last_count"] is b["last_score_sum"] is b["last_score_max"] is b["mean_last_score"] is None
     assert (b["episodes"], b["return_sum"], b["mean_episode_score"]) == (6, 300, 50.0)
     both = merge_stats([bytes(full), bytes(summary)])

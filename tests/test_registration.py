@@ -135,6 +135,35 @@ def probe():
     print("registration probe ok:", steps, "steps,", len(rec.frames), "frames")
 
 
+def probe_existing():
+    """The reference's own package was imported first (env/__init__.py:3-6 registers the same id): importing this package
+    must NOT silently take '2048-v0' over -- it warns and keeps the existing entry; an explicit register() takes it."""
+    import warnings
+    mods = gymnasium_stand_in()
+    sys.modules.update(mods)
+    gym = mods["gymnasium"]
+    gym.register(id="2048-v0", entry_point="env.envs:Game2048Env")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        import gym2048_amd as pkg
+    assert gym.registry["2048-v0"].entry_point == "env.envs:Game2048Env"
+    assert any("already registered" in str(w.message) and "env.envs:Game2048Env" in str(w.message) for w in caught), caught
+    assert pkg.register() is True and gym.registry["2048-v0"].entry_point == "gym2048_amd:Game2048Env"
+    assert pkg.register(force=False) is True          # already ours: nothing to warn about
+    print("existing registration probe ok")
+
+
+def test_import_keeps_an_existing_registration_of_the_id_and_warns():
+    if importlib.util.find_spec("gymnasium") is not None:
+        pytest.skip("the real gymnasium is installed")
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path[:0] = [%r, %r]; import test_registration as t; t.probe_existing()" % (here, os.path.dirname(here))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "existing registration probe ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_import_registers_2048_v0_and_the_registry_env_renders_for_record_video():
     if importlib.util.find_spec("gymnasium") is not None:
         pytest.skip("the real gymnasium is installed: tests/test_host_logic.py::test_real_gymnasium_and_sb3_accept_the_drop_ins covers it")
