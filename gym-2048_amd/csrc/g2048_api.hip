@@ -992,14 +992,12 @@ int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *
         return rc;
     if (io->terminal_boards || io->obs || io->boards_out)
         return fail(G2048_ERR_INVALID, "g2048_rollout_fused writes neither terminal_boards, boards_out nor obs");
-    if (e->st.rng)
-        return fail(G2048_ERR_INVALID, "g2048_rollout_fused draws from the spawn stream; not available in numpy-RNG mode");
     if (k_steps == 0)
         return G2048_OK;
     G2048_HIP(hipSetDevice(e->device));
     e->t += 1; // transaction of the first fused step
     e->fresh = 0;
-    g2048::StepArgs a = make_args(e, io, auto_reset);
+    g2048::StepArgs a = make_args(e, io, auto_reset); // (numpy-RNG mode: a.st.rng selects rollout_fused_numpy_kernel)
     a.k_steps = k_steps;
     G2048_HIP(g2048::launch_rollout_fused(a, io->action_dtype, stride, static_cast<hipStream_t>(stream)));
     e->t += k_steps - 1;
@@ -1012,14 +1010,15 @@ int g2048_rollout_random(g2048_engine *e, uint32_t k_steps, void *stream)
         return rc;
     if (k_steps == 0)
         return G2048_OK;
-    if (e->st.rng)
-        return fail(G2048_ERR_INVALID, "g2048_rollout_random draws from the spawn stream; not available in numpy-RNG mode");
     G2048_HIP(hipSetDevice(e->device));
     e->t += 1; // transaction of the first fused step
     e->fresh = 0;
     g2048::StepArgs a = make_args(e, nullptr, 1);
     a.k_steps = k_steps;
-    G2048_HIP(g2048::launch_rollout_random(a, static_cast<hipStream_t>(stream)));
+    if (e->st.rng) // numpy-RNG mode: the fused form of that mode with the synthetic policy and no per-step output
+        G2048_HIP(g2048::launch_rollout_fused(a, G2048_ACT_RANDOM, 0, static_cast<hipStream_t>(stream)));
+    else
+        G2048_HIP(g2048::launch_rollout_random(a, static_cast<hipStream_t>(stream)));
     e->t += k_steps - 1;
     return G2048_OK;
 }

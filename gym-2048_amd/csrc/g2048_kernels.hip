@@ -908,6 +908,134 @@ __global__ void __launch_bounds__(kNumpyBlock) step_numpy_kernel(const StepArgs 
     }
 }
 
+// ---- k steps of numpy-RNG mode in ONE launch, record and generator in registers (g2048_rollout_fused / _random)
+// A reset in this mode is two ~1 000-instruction spawns that only the 7 % of the lanes whose episode ended need: the
+// per-step kernel above compacts them over the block, which a kernel that keeps its boards in registers cannot do without
+// shipping generators through LDS twice per step.  Instead the lanes of a wavefront are allowed to DRIFT IN TIME: every
+// trip of the loop is one lockstep spawn, and each lane spends it on what IT needs next --
+//   * a lane that is stepping plays its own step j (its own row of the [k][n] buffers) and spawns that step's tile;
+//   * a lane whose move was illegal spawns nothing in its step (game2048_env.py:91-95), so it draws the FIRST tile of its
+//     reset in the same trip, and the second one in the next trip while its neighbours play their next step;
+//   * a lane whose episode ended on a legal move (no moves left / max_tile) spends the next two trips on its reset;
+// and the loop ends when every lane has played k steps and finished its resets.  A board's generator is consumed in exactly
+// the reference's order (step spawn, then the reset's two), whatever its neighbours do.  Under a random policy a lane
+// resets ~0.07 times per step, nearly always after an illegal move: ~1.1 trips per step instead of the 3 an in-lane reset
+// would cost every wavefront.  The price is I/O that is no longer coalesced once the lanes have drifted apart (each lane
+// reads / writes ITS row j): 6 B per env-step through partially written lines, which the L2 and the Infinity Cache merge.
+template <int ACT>
+__global__ void __launch_bounds__(kBlock) rollout_fused_numpy_kernel(const StepArgs p, uint64_t stride)
+{
+    const uint32_t i_raw = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_raw < p.n;
+    const uint32_t i = valid ? i_raw : p.n - 1u;
+    Board rec = load_board(p.st.boards, i);
+    Pcg64 rng = load_rng(p.st.rng, p.n, i);
+    const EpisodeCounters counters = load_episode_counters(p, i_raw);
+    const uint64_t t0 = (static_cast<uint64_t>(p.t_hi) << 32) | p.t_lo; // transaction of this lane's step 0
+    const uint32_t k = p.k_steps;
+    uint32_t j = 0;        // the step this lane plays next
+    uint32_t phase = 0;    // 0: stepping; 1: reset pending, no tile drawn yet; 2: reset pending, first tile drawn
+    Board fresh{{0u, 0u, 0u, 0u}};
+    uint32_t fresh_fours = 0;
+    uint32_t episodes = 0, illegal_ends = 0, gained32 = 0;
+    unsigned long long gained = 0;
+    bool last_ended = false; // this lane's step k - 1 ended its episode (the pending mark when auto_reset == 0)
+    bool bad_action = false;
+    uint32_t bad_raw = 0;
+    for (;;) {
+        const bool stepping = phase == 0u && j < k;
+        if (!g2048_any(stepping || phase != 0u)) // (wave-uniform)
+            break;
+        // ---- the step's move (lanes that are stepping)
+        uint32_t gain = 0;
+        bool legal = false;
+        Board cells = record_cells(rec);
+        const size_t io_idx = static_cast<size_t>(j < k ? j : 0u) * stride + i;
+        if (stepping) {
+            uint32_t action;
+            if constexpr (ACT == 0) {
+                const uint64_t t = t0 + j;
+                action = philox4x32_10(static_cast<uint32_t>(t), static_cast<uint32_t>(t >> 32), p.board_offset + i, 0u, p.seed_lo,
+                                       p.seed_hi).w[3] >> 30;
+            } else {
+                const typename RawAction<ACT>::type v = load_action_at<ACT>(p.actions, io_idx);
+                typedef typename std::make_unsigned<typename RawAction<ACT>::type>::type U;
+                if (static_cast<U>(v) > static_cast<U>(3)) {
+                    bad_action = true;
+                    bad_raw = static_cast<uint32_t>(v);
+                }
+                action = static_cast<uint32_t>(v) & 3u;
+            }
+            legal = move(cells, action, gain);                                  // :85
+        }
+        // ---- the trip's ONE lockstep spawn: the step's tile, or a tile of the lane's reset
+        const bool early = stepping && !legal && p.auto_reset != 0u;            // illegal move: first reset tile now
+        const bool spawn = (stepping && legal) || early || phase != 0u;
+        Board target = (stepping && legal) ? cells : (phase == 2u ? fresh : Board{{0u, 0u, 0u, 0u}});
+        bool four = false;
+        if (spawn)
+            four = add_tile_numpy(target, rng);                                 // :88 / :108 / :109
+        // ---- what the spawn was for
+        bool fin = false;
+        if (stepping) {
+            bool end = false;
+            if (legal) {
+                cells = target;
+                end = is_end(cells, p.max_exp);                                 // :89
+            }
+            const bool terminated = legal ? end : true;                         // :89, :94
+            record_update(rec, cells, (legal && four) ? 0x80u : 0u);            // a spawned 4: deficit += 4
+            gained32 += gain;                                                   // :86
+            if (valid) {
+                if (p.reward)
+                    __builtin_nontemporal_store(legal ? static_cast<float>(gain) : p.illegal_reward, p.reward + io_idx);
+                if (p.terminated)
+                    __builtin_nontemporal_store(static_cast<uint8_t>(terminated ? 1 : 0), p.terminated + io_idx);
+                if (p.illegal)
+                    __builtin_nontemporal_store(static_cast<uint8_t>(legal ? 0 : 1), p.illegal + io_idx);
+                if (p.highest)
+                    __builtin_nontemporal_store(static_cast<uint8_t>(highest(cells)), p.highest + io_idx);
+            }
+            fin = terminated && valid;
+            if (j + 1u == k)
+                last_ended = fin;
+            ++j;
+            if (terminated && p.auto_reset != 0u) {                             // the caller's `if terminated: env.reset()`
+                phase = early ? 2u : 1u;
+                fresh = target;                                                 // (early: the empty board + its first tile)
+                fresh_fours = (early && four) ? 1u : 0u;
+            }
+        } else if (phase == 1u) {
+            fresh = target;
+            fresh_fours = four ? 1u : 0u;
+            phase = 2u;
+        } else if (phase == 2u) {
+            fresh_fours += four ? 1u : 0u;
+            rec = target;                                                       // :104-109: score 0, so deficit = 4 per spawned 4
+            rec.r[2] |= fresh_fours == 1u ? 0x80u : (fresh_fours == 2u ? 0x2000u : 0u);
+            phase = 0u;
+        }
+        // episode ends of this trip (terminal record first: rec still holds it -- a reset only lands two trips later)
+        (void)record_episode_ends(p, i, fin, !legal, rec, episodes, illegal_ends);
+        if ((gained32 >> 30) != 0u) { // (a lane gains < 2^18 per step: folded long before it could wrap)
+            gained += gained32;
+            gained32 = 0;
+        }
+    }
+    gained += gained32;
+    if (valid) {
+        store_board(p.st.boards, i, rec);
+        store_rng(p.st.rng, p.n, i, rng);
+    }
+    const unsigned long long ended_last = __builtin_amdgcn_ballot_w64(last_ended);
+    flush_episode_counts(counters, episodes, illegal_ends, wave_sum64_lane63(valid ? gained : 0ull),
+                         pending_after_step(ended_last, p.auto_reset));
+    if constexpr (ACT != 0) {
+        if (p.action_err)
+            report_bad_action(p.action_err, bad_action && valid, bad_raw, p.board_offset + i);
+    }
+}
+
 // numpy's PCG64(SeedSequence(base_seed + global board index)) for every board, computed on the device.
 __global__ void __launch_bounds__(kBlock) seed_numpy_kernel(uint64_t *planes, uint32_t n, uint64_t first_seed)
 {
@@ -1862,6 +1990,16 @@ hipError_t launch_rollout_fused(const StepArgs &a, int action_dtype, uint64_t st
     if (a.n == 0 || a.k_steps == 0)
         return hipSuccess;
     const dim3 g = grid_for(a.n), b(kBlock);
+    if (a.st.rng) { // numpy-RNG mode: the lanes of a wavefront drift in time (rollout_fused_numpy_kernel)
+        switch (action_dtype) {
+        case 0: hipLaunchKernelGGL(rollout_fused_numpy_kernel<0>, g, b, 0, s, a, stride); break;
+        case 1: hipLaunchKernelGGL(rollout_fused_numpy_kernel<1>, g, b, 0, s, a, stride); break;
+        case 2: hipLaunchKernelGGL(rollout_fused_numpy_kernel<2>, g, b, 0, s, a, stride); break;
+        case 3: hipLaunchKernelGGL(rollout_fused_numpy_kernel<3>, g, b, 0, s, a, stride); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (action_dtype) {
     case 0: hipLaunchKernelGGL(rollout_fused_kernel<0>, g, b, 0, s, a, stride); break;
     case 1: hipLaunchKernelGGL(rollout_fused_kernel<1>, g, b, 0, s, a, stride); break;

@@ -264,7 +264,9 @@ int g2048_rollout_prepare(g2048_engine *e, uint32_t k_steps, const g2048_step_io
  * highest out -- in ONE launch with the boards held in registers (6 B of traffic per env-step instead
  * of 46).  For action sequences that are known in advance (replays, scripted or tree-search rollouts);
  * a policy that needs every observation uses g2048_step / g2048_rollout.  terminal_boards, boards_out and obs
- * must be NULL; not available in numpy-RNG mode. */
+ * must be NULL.  In numpy-RNG mode the generators stay in registers as well, and the lanes of a wavefront drift in time:
+ * every trip of the kernel's loop is one lockstep spawn that each lane spends on its own next step or on a tile of its own
+ * reset (a reset costs a lane one or two trips instead of costing every wavefront two spawns per step). */
 int g2048_rollout_fused(g2048_engine *e, uint32_t k_steps, const g2048_step_io *io, uint64_t stride, int auto_reset,
                         void *stream);
 
@@ -355,7 +357,7 @@ int g2048_returns_summary_async(const g2048_engine *e, g2048_stats *device_out, 
  * has_uint32 << 32 (the host computes them with numpy; SB3 seeds env i with seed + i).  After this call
  * reset/step/rollout/add_tile consume those generators; board i then plays bit-for-bit the game of the
  * unmodified reference env after reset(seed = seed_i).  planes == NULL returns to the spawn stream.
- * About 5x slower than the spawn stream; g2048_rollout_random is not available in this mode. */
+ * About 5x slower than the spawn stream (a spawn is ~1 000 instructions: a 128-bit LCG and a 15-step shuffle). */
 int g2048_set_numpy_rng(g2048_engine *e, const uint64_t *planes, void *stream);
 int g2048_get_numpy_rng(const g2048_engine *e, uint64_t *planes, void *stream);
 /* The same mode, seeded on the device: board i <- numpy PCG64(SeedSequence(base_seed + board_offset + i))

@@ -518,10 +518,15 @@ def test_argument_validation_on_device(torch_cuda):
     # a blob written before ABI 14 ("\0G2048v3") was played under the previous spawn rule: refused, with the reason
     from gym2048_amd._lib import G2048Error
     old = e.state_dict()
-    assert bytes(old["blob"][:8]) == b"\0G2048v4"
+    assert bytes(old["blob"][:8]) == b"\0G2048v5"
     old["blob"][7] = ord("3")
     with pytest.raises(G2048Error, match="before ABI 14"):
         e.load_state_dict(old)
+    old["blob"][7] = ord("4")                                    # ABI 14's blob: the same games in another slab layout
+    with pytest.raises(G2048Error, match="written by ABI 14"):
+        e.load_state_dict(old)
+    old["blob"][7] = ord("5")
+    e.load_state_dict(old)                                       # ... and the untouched one loads
     boards = e.get_boards()
     e.step(torch.full((128,), 7, dtype=torch.int64))            # only the low two bits count: 7 == left
     f = Batched2048(128, seed=1)

@@ -178,16 +178,16 @@ def test_strict_actions_report_out_of_range_values(torch_cuda, rng, dtype):
     torch.cuda.synchronize()
     with pytest.raises(G2048Error, match=r"strict actions.*board 42"):
         eng.step(None)
-    if rng == "philox":                                            # the fused form checks what it fetches as well
-        acts = rs.integers(0, 4, (9, n))
-        acts[8, 2999] = 5
-        rew = torch.zeros((9, n), dtype=torch.float32, device=eng.device)
-        eng.prepare_rollout(torch.as_tensor(acts).to(eng.device, tdt), reward=rew, fused=True).run()
-        for j in range(9):
-            ora.step((acts[j] & 3).astype(np.uint8))
-        torch.cuda.synchronize()
-        with pytest.raises(G2048Error, match=r"strict actions.*board 2999"):
-            eng.get_scores()
+    # the fused forms (both RNG modes) check what they fetch as well
+    acts = rs.integers(0, 4, (9, n))
+    acts[8, 2999] = 5
+    rew = torch.zeros((9, n), dtype=torch.float32, device=eng.device)
+    eng.prepare_rollout(torch.as_tensor(acts).to(eng.device, tdt), reward=rew, fused=True).run()
+    for j in range(9):
+        ora.step((acts[j] & 3).astype(np.uint8))
+    torch.cuda.synchronize()
+    with pytest.raises(G2048Error, match=r"strict actions.*board 2999"):
+        eng.get_scores()
     assert np.array_equal(eng.get_boards().reshape(n, 16), ora.boards)
     assert np.array_equal(eng.get_scores(), ora.score)
     # OFF (the default): the same value is played silently
@@ -225,3 +225,80 @@ def test_strict_actions_host_step_is_refused_before_stepping(torch_cuda):
             env.step(bad)
     assert np.array_equal(env.Matrix, m)
     env.step(np.int64(3))
+
+
+@pytest.mark.parametrize("auto_reset,irw,max_tile", [(True, -1.0, None), (False, 0.0, None), (True, 0.0, 64)])
+def test_numpy_rng_mode_fused_rollout_vs_oracle(torch_cuda, auto_reset, irw, max_tile):
+    """g2048_rollout_fused in numpy-RNG mode (record AND generator in registers, the lanes of a wavefront drifting in
+    time: a lane resets in its own one or two trips of the loop while its neighbours go on stepping) == the C oracle's
+    numpy mode stepped one step at a time: every per-step output at [j][i], the final boards, scores, generator states,
+    the episode books -- for a ragged batch, with and without auto-reset, with max_tile, int64 actions."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    from oracle import OracleBatch
+    n, seed, k = 4133, 19, 97
+    eng = Batched2048(n, seed=seed, rng="numpy", illegal_move_reward=irw, max_tile=max_tile)
+    ob = OracleBatch(n, seed, threads=8)
+    ob.illegal_move_reward = irw
+    ob.max_exp = int(np.log2(max_tile)) if max_tile else 0
+    ob.seed_numpy(seed)
+    eng.reset()
+    ob.reset_numpy()
+    rs = np.random.default_rng(8)
+    acts = rs.integers(0, 4, (k, n))
+    dev = eng.device
+    rew = torch.full((k, n), -7.0, dtype=torch.float32, device=dev)
+    term = torch.full((k, n), 9, dtype=torch.uint8, device=dev)
+    ill = torch.full((k, n), 9, dtype=torch.uint8, device=dev)
+    high = torch.full((k, n), 99, dtype=torch.uint8, device=dev)
+    eng.prepare_rollout(torch.as_tensor(acts).to(dev), reward=rew, terminated=term, illegal=ill, highest=high,
+                        auto_reset=auto_reset, fused=True).run()
+    torch.cuda.synchronize()
+    rew, term, ill, high = (x.cpu().numpy() for x in (rew, term, ill, high))
+    for j in range(k):
+        ob.step_numpy(acts[j].astype(np.uint8), auto_reset=auto_reset)
+        assert np.array_equal(rew[j], ob.reward), j
+        assert np.array_equal(term[j], ob.terminated), j
+        assert np.array_equal(ill[j], ob.illegal), j
+        assert np.array_equal(high[j], ob.highest), j
+    assert ob.ep_count.sum() > n                                   # every board has been through resets
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ob.boards)
+    assert np.array_equal(eng.get_scores(), ob.score)
+    assert np.array_equal(eng.get_numpy_rng().T, ob.rng)
+    assert eng.clock == k
+    st = eng.episode_stats()
+    assert st["episodes"] == int(ob.ep_count.sum()) and st["return_sum"] == ob.return_sum
+    if auto_reset:
+        assert st["return_sum"] == ob.finished_return_sum
+    assert np.array_equal(eng.get_last_scores()[ob.ep_count > 0], ob.last_score[ob.ep_count > 0])
+    # ... and the per-step form goes on from there in step with the oracle (nothing is left half-reset)
+    for s in range(6):
+        a = rs.integers(0, 4, n)
+        eng.step(torch.as_tensor(a).to(dev), auto_reset=auto_reset)
+        ob.step_numpy(a.astype(np.uint8), auto_reset=auto_reset)
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ob.boards) and np.array_equal(eng.get_numpy_rng().T, ob.rng)
+
+
+def test_numpy_rng_mode_rollout_random_and_fused_equal_per_step_at_scale(torch_cuda):
+    """2^18 boards x 160 steps in numpy-RNG mode three ways -- g2048_rollout (one launch per step), g2048_rollout_fused
+    over the same [k][n] actions, g2048_rollout_random (the synthetic policy drawn in the kernel) -- identical boards,
+    scores, generators, per-step outputs and books."""
+    torch = torch_cuda
+    from gym2048_amd.batched import Batched2048
+    n, seed, k = 1 << 18, 4, 160
+    a, b, c = (Batched2048(n, seed=seed, rng="numpy") for _ in range(3))
+    for e in (a, b, c):
+        e.reset()
+    acts = a.random_actions(k)
+    dev = a.device
+    ra, rb = (torch.zeros((k, n), dtype=torch.float32, device=dev) for _ in range(2))
+    ta, tb = (torch.zeros((k, n), dtype=torch.uint8, device=dev) for _ in range(2))
+    a.rollout(acts, reward=ra, terminated=ta)
+    b.rollout(acts, reward=rb, terminated=tb, fused=True)
+    c.rollout_random(k)
+    torch.cuda.synchronize()
+    assert torch.equal(ra, rb) and torch.equal(ta, tb) and int(ta.sum()) > n
+    for other in (b, c):
+        assert torch.equal(a.boards(), other.boards()) and torch.equal(a.scores(), other.scores())
+        assert np.array_equal(a.get_numpy_rng(), other.get_numpy_rng())
+        assert a.episode_stats() == other.episode_stats() and a.clock == other.clock == k
