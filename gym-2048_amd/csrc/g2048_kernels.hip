@@ -816,7 +816,12 @@ __device__ __forceinline__ void store_rng(uint64_t *planes, uint32_t n, uint32_t
 // the other seven retire -- each reset one listed board and store its fresh record and generator.  The reset work of
 // a block overlaps the step work of the other blocks on the CU.
 // (512 lanes: 45.0-46.1 us per step at 2^20 boards against 48.2 / 48.7 / 48.4 for 256 / 768 / 1 024, one box,
-//  profiles/r06_d_numpy_block_ab.txt; forcing 8 waves per SIMD -- 64 VGPRs, five dwords spilled -- changes nothing)
+//  profiles/r06_d_numpy_block_ab.txt; forcing 8 waves per SIMD -- 64 VGPRs, five dwords spilled -- changes nothing.
+//  Measured "no", same round: a software pipeline over 2 / 4 / 8 tiles per block with the next tile's records and generators
+//  prefetched into registers and a ninth, reset-only wavefront: 65 / 61 / 59 us -- 89 VGPRs leave four stepping wavefronts
+//  per SIMD and the serial 128-bit multiply chains need six to fill the VALU, profiles/r06_g_numpy_tiles_ab.txt; starting
+//  the odd blocks 3.4 us late to pull the load / compute / store phases of co-resident blocks apart: +10 us,
+//  profiles/r06_h_numpy_stagger_ab.txt.  What does help is not touching memory per step at all: rollout_fused_numpy_kernel.)
 constexpr uint32_t kNumpyBlock = 512;
 static_assert(kNumpyBlock == kSlotBlockLanes, "the slot array is sized for whole blocks of this kernel");
 

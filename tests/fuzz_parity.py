@@ -85,8 +85,8 @@ def one_case(case):
     for call in range(int(rs.integers(12, 40))):
         kind = str(rs.choice(["step", "rollout", "fused", "random", "host", "mask_reset", "set_boards", "state", "set_scores", "replay"],
                              p=[0.26, 0.16, 0.13, 0.08, 0.1, 0.06, 0.04, 0.06, 0.03, 0.08]))
-        if numpy_mode and kind in ("fused", "random", "mask_reset", "replay"):   # spawn-stream-only calls / unmaskable oracle reset
-            kind = "step"
+        if numpy_mode and kind in ("mask_reset", "replay"):   # unmaskable oracle reset / spawn-stream-only graph replays
+            kind = "step"                                      # (fused and random rollouts exist in numpy-RNG mode since round 6)
         where = f"{tag} call {call} {kind}"
         bump(kind)
         if kind == "step":

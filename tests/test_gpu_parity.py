@@ -477,8 +477,13 @@ def test_numpy_rng_mode_vs_oracle_and_generator_state(torch_cuda):
     other.load_state_dict(state)
     other.step(None)
     assert np.array_equal(other.get_boards(), ref) and other.rng_mode == "numpy"
-    with pytest.raises(Exception):
-        eng.rollout_random(4)
+    # g2048_rollout_random exists in this mode since round 6 (the fused kernel with the synthetic policy): the oracle,
+    # stepped one step at a time with the same policy, ends on the same boards and generators
+    ob.step_numpy(None)                                            # (the step taken above, after the checkpoint)
+    eng.rollout_random(7)
+    for _ in range(7):
+        ob.step_numpy(None)
+    assert np.array_equal(eng.get_boards().reshape(n, 16), ob.boards) and np.array_equal(eng.get_numpy_rng().T, ob.rng)
 
 
 def test_single_env_numpy_mode_is_the_reference_env(torch_cuda):
