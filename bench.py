@@ -849,19 +849,35 @@ def main():
             extras["policy_loop"] = bench_policy.run(boards=B, steps=10, warmup=2)
         except Exception as exc:  # pragma: no cover
             extras["policy_loop"] = {"error": str(exc)}
-        # (b2) numpy-compatible RNG mode (the reference's own PCG64 per board, seeded on the device)
+        # (b2) numpy-compatible RNG mode (the reference's own PCG64 per board, seeded on the device; board i == the unmodified
+        #      reference env after reset(seed = 42 + i)): one launch per step (what a policy in the loop uses) and the fused
+        #      k-step form over the same [k][B] actions (record and generator in registers, lanes drifting in time)
         try:
-            nn, kn = 1 << 20, 20
+            nn, kn = 1 << 20, 32
             npe = Batched2048(nn, device=local_rank, seed=SEED, rng="numpy")
             npe.reset()
             an = npe.random_actions(kn)
-            npe.rollout(an[:5])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            npe.rollout(an)
-            torch.cuda.synchronize()
-            extras["numpy_rng_mode_steps_per_s"] = kn * nn / (time.perf_counter() - t1)
+            rn = torch.zeros((kn, nn), dtype=torch.float32, device=dev)
+            tn = torch.zeros((kn, nn), dtype=torch.uint8, device=dev)
+            res = {}
+            for form, fused in (("per_step", False), ("fused", True)):
+                nplan = npe.prepare_rollout(an, reward=rn, terminated=tn, fused=fused)
+                nplan.run()
+                torch.cuda.synchronize()
+                best = None
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    nplan.run()
+                    torch.cuda.synchronize()
+                    dtn = time.perf_counter() - t1
+                    best = dtn if best is None else min(best, dtn)
+                res[form] = {"steps_per_s": kn * nn / best, "us_per_step": best / kn * 1e6, "launches_per_step": 0 if fused else 1}
+            res["per_step"]["algorithmic_bytes_per_env_step"] = 102      # record 16 + 16, generator 40 in + 24 out, action 1, reward 4, terminated 1
+            res["per_step"]["frac_of_hbm_peak"] = 102 * nn / (res["per_step"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            extras["numpy_rng_mode"] = res
+            extras["numpy_rng_mode_steps_per_s"] = res["per_step"]["steps_per_s"]
             npe.close()
+            del an, rn, tn, nplan
         except Exception as exc:  # pragma: no cover
             extras["numpy_rng_mode_steps_per_s"] = f"error: {exc}"
         # (b3) the drop-in single env (host arrays, one library call per step through the engine's pinned host block):

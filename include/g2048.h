@@ -172,7 +172,8 @@ int g2048_set_max_tile(g2048_engine *e, int max_exp);
  * plays the low two bits but reports it to a per-engine error word in pinned host memory, and the NEXT call on the engine that
  * starts after that launch has completed returns G2048_ERR_INVALID (naming one offending board), does nothing else, and clears
  * the report.  Costs one compare per lane, and the launches use the general step kernel instead of the reward + terminated
- * specialisation (and no cached graph): +N us per launch at 2^20 boards; default OFF.  G2048_ACT_RANDOM is never checked.
+ * specialisation (and no cached graph): nothing measurable at 2^20 boards (9.60 against 9.56 us per launch,
+ * profiles/r06_i_strict_probe.txt); default OFF, as the reference.  G2048_ACT_RANDOM is never checked.
  * g2048_step_host reads its actions from host memory and refuses BEFORE stepping anything. */
 int g2048_set_strict_actions(g2048_engine *e, int enable);
 int g2048_get_strict_actions(const g2048_engine *e);
@@ -346,8 +347,8 @@ int g2048_episode_stats_async(const g2048_engine *e, g2048_stats *device_out, vo
  * else: episodes, illegal_ends and the exact return_sum, from the episode slots and the live records.  The terminal
  * records are not read and the histogram is not counted: last_score_max is written as -1 = NOT COMPUTED (no score can be
  * negative; check it before dividing last_score_sum by last_count), last_count, last_score_sum, max_exp and highest_hist[]
- * as zero.  ONE launch (at most 256 blocks of 1 024 lanes, merged inside the launch by "last block out"): N us at 2^20
- * boards against 21 us for the full reduction. */
+ * as zero.  ONE launch (at most 256 blocks of 1 024 lanes, merged inside the launch by "last block out"): 7.4 us per call
+ * at 2^20 boards (6.5 us behind a launch train) against 21 us for the full reduction (profiles/r06_b_stats_probe_one_launch.txt). */
 int g2048_returns_summary_async(const g2048_engine *e, g2048_stats *device_out, void *stream);
 
 /* numpy-compatible RNG mode: every board draws from its OWN numpy PCG64 exactly as the reference does
@@ -407,8 +408,8 @@ int g2048_allgather_returns(const g2048_engine *e, g2048_comm *c, int32_t *out, 
  * this engine's shard (g2048_returns_summary_async: one launch), written straight into row `rank` of out[world] (device
  * memory), and ONE in-place ncclAllGather of the sizeof(g2048_stats)-byte rows -- both enqueued on `stream`, behind the
  * rollout's last step: no send buffer, no hop to a communication stream and back, no host synchronisation (a framework's
- * process-group all-gather of the same bytes costs two event hand-overs more: 26 -> N us per rollout with a one-rank
- * group on one MI355X, profiles/r06_*).  out[r] is rank r's summary once `stream` reaches that point, on every rank. */
+ * process-group all-gather of the same bytes costs two event hand-overs more: 22 us per rollout against 11-12 us with a one-rank
+ * group on one MI355X, and 26 us in round 5 with the summary as a kernel pair, profiles/r06_b_forced_dist_ab.txt).  out[r] is rank r's summary once `stream` reaches that point, on every rank. */
 int g2048_allgather_summary(const g2048_engine *e, g2048_comm *c, g2048_stats *out, void *stream);
 int g2048_comm_world(const g2048_comm *c);
 int g2048_comm_rank(const g2048_comm *c);
