@@ -17,8 +17,10 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or as plain
 starts the N ranks itself (self_launch: same environment, rank 0's JSON line relayed as the LAST line of stdout, worst
 exit code returned; fewer than N visible GPUs -> one clear line on stderr, exit code 2).  Rank r owns global boards
 [r*B, (r+1)*B) -- no data-path collective; one RCCL all-gather of the episodic returns at the end of the
-rollout, inside the timed region and enqueued on the launch stream right behind the K step launches (the
-statistics kernel and the collective start when the last step retires; no host work in between).  The
+rollout, inside the timed region and enqueued ON THE LAUNCH STREAM right behind the K step launches: ONE summary
+launch writing into this rank's row + ONE in-place ncclAllGather through the library's own communicator
+(g2048_allgather_summary; G2048_BENCH_COLLECTIVE=torch selects torch.distributed's all_gather_into_tensor instead:
+11.5-12.3 against 22-27 us with a one-rank group, profiles/r06_j_forced_dist_runs.txt; `config.collective_path`).  The
 all-gather is also the closing barrier of the timed region: no rank's copy completes before every rank has
 contributed, so each rank only synchronises its device afterwards and the elapsed times are MAX-reduced
 over ranks.  `timing` in the JSON splits the region: launch_train_us (K launches, HIP events),
@@ -27,10 +29,14 @@ scaling = "weak".  G2048_BENCH_FORCE_DIST=1 runs exactly this N > 1 code path wi
 group on a one-GPU box (init_process_group("nccl"), the device-tensor all-gather, the NCCL barrier).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- algorithmic bytes (38 B/env-step) / HIP-event time per launch vs the 8 TB/s HBM peak;
+  roofline     -- algorithmic bytes (38 B/env-step) / HIP-event time per launch vs the 8 TB/s HBM peak; `resident` says
+                  what the 2^20-board figure is a fraction of (the 38 MiB a launch touches sit in the Infinity Cache),
+                  `streaming` = the same kernel at 2^24 boards (HBM), `small_batch` = BASELINE configs[1] (65 536 boards);
                   `traffic` = HBM bytes per launch from the committed PMC profile, printed only while the
                   profile was taken from the kernel sources that are being run (hash of csrc/), else null
-  cpu_baseline -- the C oracle (oracle/, "port") timed on this box's host cores on a bounded sample; reference_estimate =
+  host         -- gc / scheduling priority of the timed regions (--nice N to change it), CPU model, physical / visible cores
+  cpu_baseline -- the C oracle (oracle/, "port") timed on this box's host cores on a bounded sample, OpenMP team calibrated
+                  (threads_tried); reference_estimate =
                   the Python port's rate here / the port-to-reference ratio measured in the build container
   timing       -- the split of the region, and k_region_repeats_us: five further regions with the same brackets
                   (`value` is the FIRST region)
