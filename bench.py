@@ -406,7 +406,23 @@ def main():
         sys.exit("G2048_BENCH_COLLECTIVE must be 'direct' or 'torch'")
     if not dist_on or backend != "nccl" or args.gather != "summary":
         collective_path = "torch"                        # gloo smoke tests (host copies) and --gather full
-    exchange = SummaryExchange(eng) if (dist_on and collective_path == "direct") else None
+    exchange, exchange_error = None, None
+    if dist_on and collective_path == "direct":
+        # the library's communicator is a SECOND RCCL communicator next to the process group's.  Should any rank fail to build
+        # it, every rank falls back to the process-group all-gather (the ranks agree through a MIN all-reduce) and the line
+        # says so -- a slower exchange is better than no scaling point
+        try:
+            exchange = SummaryExchange(eng)
+        except Exception as exc:  # pragma: no cover - needs a multi-GPU failure
+            exchange_error = f"{type(exc).__name__}: {exc}"
+        ok = torch.tensor([1 if exchange is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if exchange is not None:
+                exchange.close()
+                exchange = None
+            collective_path = "torch"
+            exchange_error = exchange_error or "another rank could not build the library's communicator"
 
     def gather_returns():
         """The path's only exchange, once per rollout: every rank reduces the episodic returns of its shard on
@@ -501,7 +517,8 @@ def main():
         # the path's only exchange: once per rollout, N > 1 only.  Enqueued behind the last step launch; at N > 1 it is
         # also the closing barrier (an all-gather completes on no rank before every rank has contributed)
         rows = gather_returns() if dist_on else None
-        ev2.record()
+        if dist_on:
+            ev2.record()                                     # (N = 1 has no exchange to bracket: one marker packet less behind the train)
         # closing bracket: [collective +] the host learns that the device is done.  By default through the library's
         # completion word (g2048_stream_signal / g2048_stream_wait: a one-wave kernel behind everything above publishes a
         # ticket to pinned host memory with a system-scope release, the host polls it) -- the same guarantee as a stream
@@ -579,6 +596,7 @@ def main():
                                          if collective_path == "direct" else
                                          "g2048_returns_summary_async + torch.distributed.all_gather_into_tensor") if args.gather == "summary"
                                         else "g2048_get_last_scores + torch.distributed.all_gather_into_tensor") if dist_on else None),
+                   "collective_path_fallback": exchange_error,
                    "collective": ((f"one all-gather per rollout of the per-rank return summaries (g2048_stats, {stats_bytes} B each)"
                                    if args.gather == "summary" else "one all-gather per rollout of the per-board episodic returns (int32[B] each)")
                                   if dist_on else "none")},
