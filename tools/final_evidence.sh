@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, final evidence of the committed sources: profile set (per size + policy), bench lines, forced-dist runs, GPU suite
+# final evidence of the committed sources (run on the GPU box: gpurun -- bash tools/final_evidence.sh <tag>; then tools/collect_profile.sh <tag>): profile set (per size + policy), bench lines, forced-dist runs, GPU suite
 set -u
 TAG=${1:-r06_j}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=$R/gpurun_out/final_$TAG; mkdir -p $O
