@@ -89,10 +89,12 @@ __global__ void __launch_bounds__(256) lane16_kernel(uint4 *boards, const uint8_
     const unsigned long long em = __ballot(nv == 0u);
     const uint32_t emask = static_cast<uint32_t>(em >> base) & 0xffffu;
     const uint32_t n_empty = __popc(emask);
-    const uint32_t k = __umulhi(w.w[0], n_empty);
+    // the spawn rule of ABI 14 (g2048.h "Randomness"): p = w * n; cell = p >> 32, a 2 iff (uint32_t)p <= 3865470566
+    const unsigned long long prod = static_cast<unsigned long long>(w.w[0]) * n_empty;
+    const uint32_t k = static_cast<uint32_t>(prod >> 32);
     const uint32_t my_rank = __popc(emask & ((1u << c) - 1u));
     if (legal && nv == 0u && my_rank == k)
-        nv = ((w.w[0] & 0xffffu) <= 58982u) ? 1u : 2u;
+        nv = (static_cast<uint32_t>(prod) <= kTwoThreshold) ? 1u : 2u;
     // ---- done detection (:262-280): full board without equal neighbours
     bool end = false;
     if (legal && n_empty == 1u) {
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) lane16_kernel(uint4 *boards, const uint8_
     if (term) {
         const uint32_t w1 = legal ? w.w[1] : w.w[0], w2 = legal ? w.w[2] : w.w[1];
         const uint32_t p1 = w1 >> 28, k2 = __umulhi(w2, 15u), p2 = k2 + (k2 >= p1 ? 1u : 0u);
-        nv = c == p1 ? (((w1 & 0xffffu) <= 58982u) ? 1u : 2u) : (c == p2 ? (((w2 & 0xffffu) <= 58982u) ? 1u : 2u) : 0u);
+        nv = c == p1 ? (fresh_is_four_16(w1) ? 2u : 1u) : (c == p2 ? (fresh_is_four_15(w2) ? 2u : 1u) : 0u);
     }
     // ---- back through LDS, the cell-0 lane stores the 16 bytes and the step outputs
     s_stage[lb][c] = static_cast<uint8_t>(nv);
