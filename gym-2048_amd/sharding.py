@@ -104,6 +104,10 @@ class SummaryExchange:
         self._engine = engine
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
+        if world > 1 and torch.cuda.device_count() < 2:
+            # ncclCommInitRank refuses two ranks on one device ("Duplicate GPU detected") -- and may leave the other ranks
+            # waiting inside the rendezvous: say so before anybody enters it (one-GPU smoke tests use allgather_stats)
+            raise ValueError(f"SummaryExchange needs one GPU per rank: {world} ranks, {torch.cuda.device_count()} visible device(s)")
         ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
         if rank == 0:
             _lib.check(self._lib.g2048_comm_unique_id(ident))
